@@ -1,0 +1,315 @@
+/*
+ * rt_hip.h - C ABI of the MI355X render core (librt_hip.so).
+ *
+ * This is the drop-in boundary for ONE hot path of deadalusai/raytracer: the
+ * per-pixel render loop of crate `raytracer-impl`
+ * (raytracer-impl/src/implementation.rs:638-661 and everything it calls) as
+ * driven by the worker loop of the UI crate (src/render.rs:130-164).
+ *
+ * The reference has no FFI; the seam is the Rust function boundary between
+ * `raytracer-ui` and `raytracer-impl`.  Every entry point below cites the
+ * reference interface it replaces.  Plain pointers and sizes only.
+ *
+ * Conventions
+ *   - all functions returning `int` return 0 on success, a negative RT_E_* code
+ *     otherwise; rt_last_error() then gives a thread-local message.  Nothing
+ *     throws or aborts across this boundary.
+ *   - `RtScene*` is opaque, immutable after creation and may be used from
+ *     several host threads at once (calls are serialised per scene).
+ *   - output buffers are caller allocated.
+ */
+#ifndef RT_HIP_H
+#define RT_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_ABI_VERSION 1
+
+/* ---- error codes -------------------------------------------------------- */
+#define RT_OK            0
+#define RT_E_INVALID    -1   /* bad argument / malformed scene description     */
+#define RT_E_HIP        -2   /* a HIP runtime call failed                      */
+#define RT_E_NO_DEVICE  -3   /* no GPU visible                                  */
+#define RT_E_DEPTH      -4   /* BVH deeper than the traversal stack can hold
+                                (reference: ArrayVec<State,30> panic, bvh.rs:192) */
+#define RT_E_IO         -5   /* file could not be read (sample scenes / OBJ)    */
+#define RT_E_LIMIT      -6   /* size beyond a documented maximum                */
+
+/* ---- POD vector types (types.rs:11-12, :254-255) ------------------------ */
+typedef struct RtV3 { float x, y, z; } RtV3;
+typedef struct RtV2 { float x, y; } RtV2;
+
+/* ---- Camera (implementation.rs:451-459): the already-derived basis ------ */
+typedef struct RtCamera {
+    RtV3  lower_left_corner;
+    RtV3  horizontal;
+    RtV3  vertical;
+    RtV3  origin;
+    RtV3  u;
+    RtV3  v;
+    float lens_radius;
+} RtCamera;
+
+/* ---- Hitables (shapes/sphere.rs:19-23, plane.rs:19-26, mesh.rs:104-148) -- */
+enum { RT_HITABLE_SPHERE = 0, RT_HITABLE_PLANE = 1, RT_HITABLE_MESH = 2 };
+
+typedef struct RtSphere {
+    float    radius;
+    uint32_t mat_id;
+    uint32_t tex_id;
+} RtSphere;
+
+typedef struct RtPlane {
+    RtV3     normal;      /* unit */
+    RtV3     u_basis;
+    RtV3     v_basis;
+    float    radius;      /* used only when has_radius != 0 (disk) */
+    uint32_t has_radius;
+    uint32_t mat_id;
+    uint32_t tex_id;
+} RtPlane;
+
+/* MeshTri (mesh.rs:114-123). tex_key: -1 = None. */
+typedef struct RtMeshTri {
+    RtV3    a, b, c;
+    RtV2    a_uv, b_uv, c_uv;
+    int32_t tex_key;
+} RtMeshTri;
+
+/* Mesh (mesh.rs:104-106): geometry shared by every MeshObject that names it
+ * (the Arc<MeshBvhRoot> of mesh.rs:141-158 => instancing). */
+typedef struct RtMesh {
+    const RtMeshTri* tris;
+    uint64_t         tri_count;
+} RtMesh;
+
+typedef struct RtMeshObject {
+    uint32_t mesh_index;  /* into RtSceneDesc.meshes */
+    uint32_t mat_id;
+    uint32_t tex_id;
+} RtMeshObject;
+
+/* ---- Entity (implementation.rs:213-230) --------------------------------- */
+typedef struct RtRotation { RtV3 axis; float theta; } RtRotation;
+
+typedef struct RtEntity {
+    uint32_t hitable_kind;      /* RT_HITABLE_*                               */
+    uint32_t hitable_index;     /* into spheres / planes / mesh_objects       */
+    int32_t  id;                /* Entity.id, -1 = None                       */
+    uint32_t translation_first; /* into RtSceneDesc.translations              */
+    uint32_t translation_count;
+    uint32_t rotation_first;    /* into RtSceneDesc.rotations                 */
+    uint32_t rotation_count;
+} RtEntity;
+
+/* ---- Materials (materials.rs:26-28, :56-59, :115-119) -------------------- */
+enum { RT_MAT_LAMBERTIAN = 0, RT_MAT_SPECULAR = 1, RT_MAT_DIELECTRIC = 2 };
+
+typedef struct RtMaterial {
+    uint32_t kind;
+    float    reflectivity;  /* Lambertian.reflectivity / Specular.reflectiveness / Dielectric.reflectivity */
+    float    fuzz;          /* Specular.fuzz       */
+    float    opacity;       /* Dielectric.opacity  */
+    float    ref_index;     /* Dielectric.ref_index */
+} RtMaterial;
+
+/* ---- Textures (texture.rs) ----------------------------------------------- */
+enum {
+    RT_TEX_COLOR = 0,        /* ColorTexture(V3)            texture.rs:9      */
+    RT_TEX_CHECKER = 1,      /* CheckerTexture{size,odd,even} texture.rs:20   */
+    RT_TEX_UV_TEST = 2,      /* UvTestTexture               texture.rs:49     */
+    RT_TEX_XYZ_TEST = 3,     /* XyzTestTexture(f32)         texture.rs:58     */
+    RT_TEX_COLOR_MAP = 4,    /* ColorMap{width,height,pixels} texture.rs:76   */
+    RT_TEX_MESH = 5,         /* MeshTexture{Ka,Kd,map}      texture.rs:102    */
+    RT_TEX_MESH_SET = 6      /* MeshTextureSet{textures}    texture.rs:120    */
+};
+
+typedef struct RtTexture {
+    uint32_t kind;
+    RtV3     color;       /* COLOR: value; MESH: diffuse_color                 */
+    RtV3     color2;      /* MESH: ambient_color                               */
+    float    size;        /* CHECKER: size; XYZ_TEST: max                      */
+    int32_t  child0;      /* CHECKER: odd tex; MESH: color map tex (-1 = None);
+                             MESH_SET: first entry in RtSceneDesc.tex_set_entries */
+    int32_t  child1;      /* CHECKER: even tex; MESH_SET: entry count          */
+    uint32_t width;       /* COLOR_MAP                                         */
+    uint32_t height;      /* COLOR_MAP                                         */
+    uint64_t texel_first; /* COLOR_MAP: first texel in RtSceneDesc.texels      */
+} RtTexture;
+
+/* ---- Lights (lights.rs:9-13, :52-58, :112-116) --------------------------- */
+enum { RT_LIGHT_POINT = 0, RT_LIGHT_LAMP = 1, RT_LIGHT_DIRECTIONAL = 2 };
+
+typedef struct RtLight {
+    uint32_t kind;
+    RtV3     origin;      /* POINT, LAMP                                       */
+    RtV3     direction;   /* LAMP, DIRECTIONAL (already unit)                  */
+    RtV3     color;
+    float    intensity;
+    float    angle_deg;   /* LAMP                                              */
+} RtLight;
+
+enum { RT_SKY_DAY = 0, RT_SKY_BLACK = 1 };
+
+/* ---- Scene (implementation.rs:315-324), flattened to POD arrays ---------- *
+ * What a `describe()` over the reference's private Scene fields would emit.  */
+typedef struct RtSceneDesc {
+    uint32_t abi_version;   /* RT_ABI_VERSION */
+    RtCamera camera;
+    uint32_t sky;           /* RT_SKY_* */
+
+    const RtEntity*     entities;      uint64_t entity_count;
+    const RtV3*         translations;  uint64_t translation_count;
+    const RtRotation*   rotations;     uint64_t rotation_count;
+
+    const RtSphere*     spheres;       uint64_t sphere_count;
+    const RtPlane*      planes;        uint64_t plane_count;
+    const RtMeshObject* mesh_objects;  uint64_t mesh_object_count;
+    const RtMesh*       meshes;        uint64_t mesh_count;
+
+    const RtMaterial*   materials;     uint64_t material_count;
+    const RtTexture*    textures;      uint64_t texture_count;
+    const int32_t*      tex_set_entries; uint64_t tex_set_entry_count; /* texture ids */
+    const RtV3*         texels;        uint64_t texel_count;
+    const RtLight*      lights;        uint64_t light_count;
+} RtSceneDesc;
+
+/* ---- RenderSettings (implementation.rs:332-337) --------------------------- */
+typedef struct RtSettings {
+    uint32_t width;
+    uint32_t height;
+    uint32_t max_reflections;
+    uint32_t samples_per_pixel;
+} RtSettings;
+
+/* ---- RenderChunk (viewport.rs:5-11) --------------------------------------- */
+typedef struct RtRenderChunk {
+    uint32_t left, top, width, height;
+} RtRenderChunk;
+
+/* Ray counters. A ray = one Scene::hit_closest call (implementation.rs:372):
+ * primary (:567 at top level), secondary (:594,:602), shadow incl. continuation
+ * through transparent occluders (:535).  The reference keeps no such counter. */
+typedef struct RtRayCounters {
+    uint64_t primary;
+    uint64_t secondary;
+    uint64_t shadow;
+    uint64_t samples;
+} RtRayCounters;
+
+typedef struct RtScene RtScene;
+
+/* ---- entry points --------------------------------------------------------- */
+
+/* Number of visible GPUs (no counterpart; the reference is CPU-only). */
+int rt_device_count(void);
+
+/* Thread-local message for the last failing call on this thread.
+ * Replaces the reference's panics / CreateSceneError(String)
+ * (src/job_constructing.rs:45-53). */
+const char* rt_last_error(void);
+
+/* Replaces Scene::build_bvh (implementation.rs:377-383) + MeshBvhRoot::new
+ * (mesh.rs:84-90): validates the description, builds the TLAS over entities and
+ * one BLAS per mesh with the reference's algorithm (bvh.rs:129-188,
+ * util.rs:6-28), flattens everything and uploads it to `device`.
+ * Returns NULL on failure. */
+RtScene* rt_scene_create(const RtSceneDesc* desc, int device);
+void     rt_scene_destroy(RtScene* scene);
+
+/* Replaces the whole `for p in chunk.iter_pixels() { cast_rays_into_scene(..);
+ * put_pixel(v3_to_rgba(..)) }` loop of src/render.rs:148-159 for one chunk
+ * (chunk granularity: a per-pixel FFI call cannot feed a GPU).
+ *   rgb_out  : chunk.width*chunk.height*3 floats, row-major, the V3 returned
+ *              by cast_rays_into_scene (implementation.rs:638-661); nullable
+ *   rgba_out : chunk.width*chunk.height*4 bytes, v3_to_rgba (src/rgba.rs:6-12);
+ *              nullable
+ *   seed     : replaces XorShiftRng::seed_from_u64(12345) (render.rs:142) by
+ *              the key of a counter-based RNG addressed (seed,x,y,sample,node):
+ *              the image does not depend on chunking or GPU count.
+ *   counters : nullable; rays are ADDED to it.
+ * Host pointers; the call blocks until the pixels are in the buffers. */
+int rt_render_chunk(RtScene* scene, const RtSettings* settings,
+                    const RtRenderChunk* chunk, uint64_t seed,
+                    float* rgb_out, uint8_t* rgba_out, RtRayCounters* counters);
+
+/* Same, but outputs are DEVICE pointers on the scene's device and the work is
+ * only enqueued on `stream` (a hipStream_t, NULL = default stream); nothing is
+ * copied to the host.  `pitch_pixels` is the row pitch of the output images in
+ * pixels and (`out_x`,`out_y`) the position of the chunk inside them, so tiles
+ * can be written straight into a full framebuffer.
+ * `counters_dev` (nullable) is a device RtRayCounters that is added to. */
+int rt_render_chunk_device(RtScene* scene, const RtSettings* settings,
+                           const RtRenderChunk* chunk, uint64_t seed,
+                           void* rgb_dev, void* rgba_dev,
+                           uint32_t pitch_pixels, uint32_t out_x, uint32_t out_y,
+                           void* counters_dev, void* stream);
+
+/* spp-split rendering (partitioning 2): adds the SUM of the
+ * per-sample clamped colours (implementation.rs:635,656) of samples
+ * [sample_first, sample_first+sample_count) to accum_dev (float3 per pixel,
+ * full-frame pitch = settings.width), without dividing.  Sample indices address
+ * the counter-based RNG, so N ranks rendering disjoint ranges reproduce the
+ * samples of one rank rendering all of them. */
+int rt_accumulate_chunk_device(RtScene* scene, const RtSettings* settings,
+                               const RtRenderChunk* chunk, uint64_t seed,
+                               uint32_t sample_first, uint32_t sample_count,
+                               void* accum_dev, void* counters_dev, void* stream);
+
+/* Finishes an accumulator: rgb = accum / spp (implementation.rs:659) and
+ * rgba = v3_to_rgba(rgb) (src/rgba.rs:6-12) for n_pixels pixels. Device pointers;
+ * rgb_dev / rgba_dev nullable. */
+int rt_resolve_device(int device, const void* accum_dev, uint64_t n_pixels,
+                      uint32_t samples_per_pixel, void* rgb_dev, void* rgba_dev,
+                      void* stream);
+
+/* Parity gate 1: the first Scene::hit_closest(ray, BIAS, f32::MAX)
+ * (implementation.rs:567) of the lens-centre ray of every pixel of the chunk.
+ * Host output arrays of chunk.width*chunk.height entries (normal: x3):
+ * t (<0 = miss), world normal, entity index (scene order, -1 = miss), triangle
+ * index inside the mesh (-1 for non-mesh). Any output pointer may be NULL. */
+int rt_primary_hits(RtScene* scene, const RtSettings* settings,
+                    const RtRenderChunk* chunk,
+                    float* t_out, float* normal_out,
+                    int32_t* entity_out, int32_t* tri_out);
+
+/* create_render_chunks (viewport.rs:30-54). Writes count_x*count_y chunks in
+ * the reference's order; returns the number written or a negative error if
+ * `capacity` is too small or a count is 0. */
+int rt_create_render_chunks(uint32_t width, uint32_t height,
+                            uint32_t count_x, uint32_t count_y,
+                            RtRenderChunk* out, uint32_t capacity);
+
+/* v3_to_rgba (src/rgba.rs:6-12) on the host, for callers that kept floats. */
+void rt_v3_to_rgba(const float* rgb, uint64_t n_pixels, uint8_t* rgba_out);
+
+/* Introspection used by tests and the bench (no reference counterpart). */
+typedef struct RtSceneInfo {
+    uint64_t entity_count;
+    uint64_t mesh_count;
+    uint64_t triangle_count;        /* unique triangles over all meshes         */
+    uint64_t instanced_triangle_count; /* sum over mesh entities                */
+    uint64_t tlas_node_count;
+    uint64_t blas_node_count;
+    uint32_t tlas_depth;
+    uint32_t blas_depth;            /* deepest BLAS                             */
+    uint64_t device_bytes;          /* HBM resident bytes of the scene          */
+} RtSceneInfo;
+int rt_scene_info(const RtScene* scene, RtSceneInfo* out);
+
+/* Reference-order leaf enumeration of the TLAS (object indices in the order
+ * bvh.rs:210-236 would emit them if every box were hit).  Lets tests compare
+ * the product's BVH build against the oracle's without sharing code.
+ * mesh_index < 0: TLAS; otherwise that mesh's BLAS. Returns count written. */
+int64_t rt_scene_bvh_order(const RtScene* scene, int64_t mesh_index,
+                           uint32_t* out, uint64_t capacity);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_HIP_H */

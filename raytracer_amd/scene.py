@@ -1,0 +1,323 @@
+"""Host-side mirror of the reference's scene / settings / render-chunk API.
+
+Names follow the reference (raytracer-impl/src/implementation.rs,
+viewport.rs; raytracer-samples/src/scene.rs): ``SceneBuilder`` plays the role
+of ``Scene::new`` + ``add_*``, ``Scene`` is the built scene resident on one GPU
+(``Scene::build_bvh`` happened), ``RenderSettings`` / ``RenderChunk`` /
+``create_render_chunks`` are the reference's own.  All work happens behind the
+C ABI of include/rt_hip.h; this module only marshals arguments.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import (RtCamera, RtCameraConfig, RtEntity, RtLight, RtMaterial, RtMeshObject, RtMeshTri, RtPlane,
+                   RtRayCounters, RtRenderChunk, RtRotation, RtSceneDesc, RtSceneInfo, RtSettings, RtSphere,
+                   RtTexture, RtV3)
+
+
+class RtError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"[rt error {code}] {message}")
+        self.code = code
+
+
+def _v3(v):
+    return RtV3(float(v[0]), float(v[1]), float(v[2]))
+
+
+def _f3(v):
+    return (C.c_float * 3)(float(v[0]), float(v[1]), float(v[2]))
+
+
+class CameraConfiguration:
+    """CameraConfiguration (raytracer-samples/src/scene.rs:12-20); defaults are
+    the UI's (src/settings.rs:88-105)."""
+
+    def __init__(self, width, height, lens_radius=0.1, fov=45.0, angle_adjust_v=0.0, angle_adjust_h=0.0,
+                 focus_dist_adjust=0.0):
+        self.c = RtCameraConfig(float(width), float(height), lens_radius, fov, angle_adjust_v, angle_adjust_h,
+                                focus_dist_adjust)
+
+    def make_camera(self, look_to, default_look_from):
+        out = RtCamera()
+        rc = _ffi.load_samples().rt_make_camera(C.byref(self.c), _f3(look_to), _f3(default_look_from), C.byref(out))
+        if rc:
+            raise RtError(rc, _ffi.load_samples().rt_samples_last_error().decode())
+        return out
+
+
+def camera_new(look_from, look_at, v_fov, aspect_ratio, lens_radius, focus_dist):
+    """Camera::new (implementation.rs:462-480)."""
+    out = RtCamera()
+    _ffi.load_samples().rt_camera_new(_f3(look_from), _f3(look_at), v_fov, aspect_ratio, lens_radius, focus_dist,
+                                      C.byref(out))
+    return out
+
+
+class RenderSettings:
+    """RenderSettings (implementation.rs:332-337)."""
+
+    def __init__(self, width, height, max_reflections=5, samples_per_pixel=1):
+        self.c = RtSettings(width, height, max_reflections, samples_per_pixel)
+
+    width = property(lambda s: s.c.width)
+    height = property(lambda s: s.c.height)
+    max_reflections = property(lambda s: s.c.max_reflections)
+    samples_per_pixel = property(lambda s: s.c.samples_per_pixel)
+
+
+def RenderChunk(left, top, width, height):
+    """RenderChunk (viewport.rs:5-11)."""
+    return RtRenderChunk(left, top, width, height)
+
+
+def create_render_chunks(size, count):
+    """create_render_chunks(size, count) (viewport.rs:30-54), via the C ABI."""
+    lib = _ffi.load_hip()
+    n = max(int(count[0]) * int(count[1]), 1)
+    out = (RtRenderChunk * n)()
+    rc = lib.rt_create_render_chunks(size[0], size[1], count[0], count[1], out, n)
+    if rc < 0:
+        raise RtError(rc, lib.rt_last_error().decode())
+    return [RtRenderChunk(c.left, c.top, c.width, c.height) for c in out[:rc]]
+
+
+class SceneBuilder:
+    """Scene::new + add_entity / add_material / add_texture / add_light
+    (implementation.rs:340-370).  Owns an RtSceneBuilder of librt_samples.so."""
+
+    def __init__(self, camera=None, sky=_ffi.RT_SKY_DAY, _handle=None):
+        self._lib = _ffi.load_samples()
+        if _handle is not None:
+            self._h = _handle
+        else:
+            self._h = self._lib.rt_builder_new(C.byref(camera), sky)
+        if not self._h:
+            raise RtError(_ffi.RT_E_INVALID, self._lib.rt_samples_last_error().decode())
+
+    @classmethod
+    def sample(cls, name, camera_config, mesh_dir=None, params=None):
+        """One of the reference's sample scenes (raytracer-samples/src/lib.rs:18-37)."""
+        lib = _ffi.load_samples()
+        mesh_dir = mesh_dir or _ffi.ASSET_MESH_DIR
+        p = None
+        if params:
+            p = ";".join(f"{k}={v}" for k, v in params.items()).encode()
+        h = lib.rt_samples_create(name.encode(), C.byref(camera_config.c), mesh_dir.encode(), p)
+        if not h:
+            raise RtError(_ffi.RT_E_INVALID, lib.rt_samples_last_error().decode())
+        return cls(_handle=h)
+
+    @staticmethod
+    def sample_names():
+        lib = _ffi.load_samples()
+        return [lib.rt_samples_name(i).decode() for i in range(lib.rt_samples_count())]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.rt_builder_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _check(self, rc):
+        if rc < 0:
+            raise RtError(rc, self._lib.rt_samples_last_error().decode())
+        return rc
+
+    # -- materials (materials.rs) --
+    def add_lambertian(self, reflectivity=0.0):
+        return self._check(self._lib.rt_builder_add_material(
+            self._h, C.byref(RtMaterial(_ffi.RT_MAT_LAMBERTIAN, reflectivity, 0.0, 0.0, 0.0))))
+
+    def add_specular(self, reflectiveness=1.0, fuzz=0.0):
+        return self._check(self._lib.rt_builder_add_material(
+            self._h, C.byref(RtMaterial(_ffi.RT_MAT_SPECULAR, reflectiveness, fuzz, 0.0, 0.0))))
+
+    def add_dielectric(self, reflectivity=1.0, opacity=0.0, ref_index=1.5):
+        return self._check(self._lib.rt_builder_add_material(
+            self._h, C.byref(RtMaterial(_ffi.RT_MAT_DIELECTRIC, reflectivity, 0.0, opacity, ref_index))))
+
+    # -- textures (texture.rs) --
+    def _tex(self, **kw):
+        t = RtTexture()
+        t.child0 = t.child1 = -1
+        for k, v in kw.items():
+            setattr(t, k, v)
+        return self._check(self._lib.rt_builder_add_texture(self._h, C.byref(t)))
+
+    def add_color_texture(self, rgb):
+        return self._tex(kind=_ffi.RT_TEX_COLOR, color=_v3(rgb))
+
+    def add_checker_texture(self, size, odd_tex, even_tex):
+        return self._tex(kind=_ffi.RT_TEX_CHECKER, size=size, child0=odd_tex, child1=even_tex)
+
+    def add_uv_test_texture(self):
+        return self._tex(kind=_ffi.RT_TEX_UV_TEST)
+
+    def add_xyz_test_texture(self, max_value):
+        return self._tex(kind=_ffi.RT_TEX_XYZ_TEST, size=max_value)
+
+    def add_color_map(self, pixels):
+        """ColorMap from an (H, W, 3) float array, row 0 = top (color_map.rs:16-33)."""
+        px = np.ascontiguousarray(pixels, dtype=np.float32)
+        h, w, _ = px.shape
+        return self._check(self._lib.rt_builder_add_color_map(self._h, w, h, px.ctypes.data))
+
+    def add_mesh_texture(self, ambient, diffuse, color_map_tex=-1):
+        return self._tex(kind=_ffi.RT_TEX_MESH, color=_v3(diffuse), color2=_v3(ambient), child0=color_map_tex)
+
+    # -- lights (lights.rs) --
+    def add_point_light(self, origin, intensity=100.0, color=(1, 1, 1)):
+        l = RtLight(_ffi.RT_LIGHT_POINT, _v3(origin), RtV3(), _v3(color), intensity, 0.0)
+        return self._check(self._lib.rt_builder_add_light(self._h, C.byref(l)))
+
+    def add_lamp_light(self, origin, direction, intensity=80.0, angle_deg=45.0, color=(1, 1, 1)):
+        d = np.asarray(direction, dtype=np.float32)
+        n = np.float32(np.sqrt(np.float32(d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]))
+        if n != 0:
+            d = d / n
+        l = RtLight(_ffi.RT_LIGHT_LAMP, _v3(origin), _v3(d), _v3(color), intensity, angle_deg)
+        return self._check(self._lib.rt_builder_add_light(self._h, C.byref(l)))
+
+    def add_directional_light(self, direction, intensity=1.0, color=(1, 1, 1)):
+        d = np.asarray(direction, dtype=np.float32)
+        n = np.float32(np.sqrt(np.float32(d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]))
+        if n != 0:
+            d = d / n
+        l = RtLight(_ffi.RT_LIGHT_DIRECTIONAL, RtV3(), _v3(d), _v3(color), intensity, 0.0)
+        return self._check(self._lib.rt_builder_add_light(self._h, C.byref(l)))
+
+    # -- geometry --
+    def add_mesh(self, triangles, uvs=None, tex_keys=None):
+        """Mesh{tris} from an (N, 3, 3) float array; returns the mesh index."""
+        tri = np.asarray(triangles, dtype=np.float32)
+        n = tri.shape[0]
+        arr = (RtMeshTri * n)()
+        for i in range(n):
+            arr[i].a, arr[i].b, arr[i].c = _v3(tri[i, 0]), _v3(tri[i, 1]), _v3(tri[i, 2])
+            if uvs is not None:
+                for k, name in enumerate(("a_uv", "b_uv", "c_uv")):
+                    getattr(arr[i], name).x = float(uvs[i][k][0])
+                    getattr(arr[i], name).y = float(uvs[i][k][1])
+            arr[i].tex_key = -1 if tex_keys is None else int(tex_keys[i])
+        return self._check(self._lib.rt_builder_add_mesh(self._h, arr, n))
+
+    def load_obj(self, path):
+        """load_obj_builder(path).build_mesh() -> (mesh index, MeshTextureSet TexId)."""
+        tex = C.c_int(-1)
+        mesh = self._check(self._lib.rt_builder_load_obj(self._h, str(path).encode(), C.byref(tex)))
+        return mesh, tex.value
+
+    def _entity(self, kind, sphere, plane, mesh_object, translations, rotations, id):
+        tr = (RtV3 * max(len(translations), 1))(*[_v3(t) for t in translations])
+        ro = (RtRotation * max(len(rotations), 1))(*[RtRotation(_v3(a), float(th)) for a, th in rotations])
+        return self._check(self._lib.rt_builder_add_entity(
+            self._h, kind, sphere, plane, mesh_object, -1 if id is None else id, tr, len(translations), ro,
+            len(rotations)))
+
+    def add_sphere_entity(self, radius, mat, tex, translations=(), rotations=(), id=None):
+        """Entity::new(Sphere::new(radius, mat, tex)).translate(..).rotate(..).id(..)"""
+        return self._entity(_ffi.RT_HITABLE_SPHERE, C.byref(RtSphere(radius, mat, tex)), None, None, translations,
+                            rotations, id)
+
+    def add_plane_entity(self, normal, mat, tex, radius=None, translations=(), rotations=(), id=None):
+        p = RtPlane()
+        self._check(self._lib.rt_plane_new(_f3(normal), mat, tex, 0 if radius is None else 1,
+                                           0.0 if radius is None else radius, C.byref(p)))
+        return self._entity(_ffi.RT_HITABLE_PLANE, None, C.byref(p), None, translations, rotations, id)
+
+    def add_mesh_entity(self, mesh, mat, tex, translations=(), rotations=(), id=None):
+        return self._entity(_ffi.RT_HITABLE_MESH, None, None, C.byref(RtMeshObject(mesh, mat, tex)), translations,
+                            rotations, id)
+
+    def desc(self):
+        """The flattened POD description (valid until the builder changes)."""
+        return self._lib.rt_builder_desc(self._h)
+
+
+class Scene:
+    """A scene resident on one MI355X: Scene::build_bvh done (TLAS + one BLAS per
+    mesh), flattened and uploaded (rt_scene_create)."""
+
+    def __init__(self, builder, device=0):
+        self._lib = _ffi.load_hip()
+        self._builder = builder   # keeps the description alive during the call
+        self._h = self._lib.rt_scene_create(builder.desc(), device)
+        if not self._h:
+            raise RtError(_ffi.RT_E_INVALID, self._lib.rt_last_error().decode())
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.rt_scene_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _check(self, rc):
+        if rc < 0:
+            raise RtError(rc, self._lib.rt_last_error().decode())
+        return rc
+
+    def info(self):
+        out = RtSceneInfo()
+        self._check(self._lib.rt_scene_info(self._h, C.byref(out)))
+        return out
+
+    def bvh_order(self, mesh_index=-1):
+        n = self._check(self._lib.rt_scene_bvh_order(self._h, mesh_index, None, 0))
+        out = np.zeros(n, dtype=np.uint32)
+        self._check(self._lib.rt_scene_bvh_order(self._h, mesh_index, out.ctypes.data, n))
+        return out
+
+    def render_chunk(self, settings, chunk, seed=12345, want_rgb=True, want_rgba=True):
+        """The pixel loop of src/render.rs:148-159 for one chunk.
+        Returns (rgb float32 (h,w,3) | None, rgba uint8 (h,w,4) | None, RtRayCounters)."""
+        h, w = chunk.height, chunk.width
+        rgb = np.empty((h, w, 3), dtype=np.float32) if want_rgb else None
+        rgba = np.empty((h, w, 4), dtype=np.uint8) if want_rgba else None
+        counters = RtRayCounters()
+        self._check(self._lib.rt_render_chunk(
+            self._h, C.byref(settings.c), C.byref(chunk), seed,
+            rgb.ctypes.data if want_rgb else None, rgba.ctypes.data if want_rgba else None, C.byref(counters)))
+        return rgb, rgba, counters
+
+    def render_chunk_device(self, settings, chunk, seed, rgb_ptr, rgba_ptr, pitch_pixels, out_x, out_y,
+                            counters_ptr=None, stream=None):
+        self._check(self._lib.rt_render_chunk_device(self._h, C.byref(settings.c), C.byref(chunk), seed, rgb_ptr,
+                                                     rgba_ptr, pitch_pixels, out_x, out_y, counters_ptr, stream))
+
+    def accumulate_chunk_device(self, settings, chunk, seed, sample_first, sample_count, accum_ptr,
+                                counters_ptr=None, stream=None):
+        self._check(self._lib.rt_accumulate_chunk_device(self._h, C.byref(settings.c), C.byref(chunk), seed,
+                                                         sample_first, sample_count, accum_ptr, counters_ptr, stream))
+
+    def primary_hits(self, settings, chunk):
+        """(t, normal, entity index, triangle index) of the first hit_closest per pixel."""
+        h, w = chunk.height, chunk.width
+        t = np.empty((h, w), dtype=np.float32)
+        n = np.empty((h, w, 3), dtype=np.float32)
+        e = np.empty((h, w), dtype=np.int32)
+        tri = np.empty((h, w), dtype=np.int32)
+        self._check(self._lib.rt_primary_hits(self._h, C.byref(settings.c), C.byref(chunk), t.ctypes.data,
+                                              n.ctypes.data, e.ctypes.data, tri.ctypes.data))
+        return t, n, e, tri
+
+
+def resolve_device(device, accum_ptr, n_pixels, samples_per_pixel, rgb_ptr, rgba_ptr, stream=None):
+    lib = _ffi.load_hip()
+    rc = lib.rt_resolve_device(device, accum_ptr, n_pixels, samples_per_pixel, rgb_ptr, rgba_ptr, stream)
+    if rc < 0:
+        raise RtError(rc, lib.rt_last_error().decode())
+
+
+def v3_to_rgba(rgb):
+    """v3_to_rgba (src/rgba.rs:6-12) over an (..., 3) float array."""
+    lib = _ffi.load_hip()
+    a = np.ascontiguousarray(rgb, dtype=np.float32)
+    out = np.empty(a.shape[:-1] + (4,), dtype=np.uint8)
+    lib.rt_v3_to_rgba(a.ctypes.data, a.size // 3, out.ctypes.data)
+    return out

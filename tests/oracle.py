@@ -1,0 +1,171 @@
+"""ctypes binding of oracle/librt_oracle.so - TEST INFRASTRUCTURE ONLY.
+
+The oracle is the CPU restatement of the reference (oracle/rt_oracle.cpp).  Only
+tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from raytracer_amd import _ffi
+from raytracer_amd._ffi import RtCamera, RtLight, RtMeshTri, RtRayCounters, RtRenderChunk, RtSceneDesc, RtSettings
+
+ORACLE_DIR = os.path.join(_ffi.REPO_ROOT, "oracle")
+ORACLE_LIB = os.path.join(ORACLE_DIR, "librt_oracle.so")
+
+ORC_RNG_XORSHIFT_CHUNK, ORC_RNG_COUNTER = 0, 1
+PURPOSE_LENS, PURPOSE_PATH, PURPOSE_SHADOW = 0, 1, 2
+
+
+class OrcCounters(C.Structure):
+    _fields_ = [("rays", RtRayCounters)] + [(n, C.c_uint64) for n in (
+        "ref_nodes", "ref_spheres", "ref_planes", "ref_tris", "ref_xforms",
+        "min_nodes", "min_spheres", "min_planes", "min_tris", "min_xforms", "min_instances", "min_mismatch")]
+
+
+_P = C.POINTER
+_f32p = _P(C.c_float)
+_PROTOS = {
+    "orc_last_error": (C.c_char_p, []),
+    "orc_scene_create": (C.c_void_p, [_P(RtSceneDesc)]),
+    "orc_scene_destroy": (None, [C.c_void_p]),
+    "orc_render_chunk": (C.c_int, [C.c_void_p, _P(RtSettings), _P(RtRenderChunk), C.c_int, C.c_uint64, C.c_uint32,
+                                   C.c_int, C.c_void_p, C.c_void_p, _P(OrcCounters)]),
+    "orc_accumulate_chunk": (C.c_int, [C.c_void_p, _P(RtSettings), _P(RtRenderChunk), C.c_uint64, C.c_uint32,
+                                       C.c_uint32, C.c_void_p]),
+    "orc_render_image_mt": (C.c_int, [C.c_void_p, _P(RtSettings), C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
+                                      C.c_uint64, C.c_void_p, C.c_void_p, _P(OrcCounters), _P(C.c_double)]),
+    "orc_render_chunks_mt": (C.c_int, [C.c_void_p, _P(RtSettings), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                       C.c_uint32, C.c_int, C.c_uint64, C.c_int, _P(OrcCounters), _P(C.c_double)]),
+    "orc_primary_hits": (C.c_int, [C.c_void_p, _P(RtSettings), _P(RtRenderChunk), C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p]),
+    "orc_scene_bvh_order": (C.c_int64, [C.c_void_p, C.c_int64, C.c_void_p, C.c_uint64]),
+    "orc_scene_bvh_depth": (C.c_int, [C.c_void_p, C.c_int64]),
+    "orc_partition_by_key_i32": (C.c_int, [_P(C.c_int32), C.c_int, C.c_int32]),
+    "orc_create_render_chunks": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _P(RtRenderChunk), C.c_uint32]),
+    "orc_intersect_sphere": (C.c_int, [_f32p, _f32p, C.c_float, _f32p]),
+    "orc_sphere_hit": (C.c_float, [_f32p, _f32p, C.c_float, C.c_float, C.c_float, _f32p]),
+    "orc_try_hit_tri": (C.c_int, [_f32p, _f32p, C.c_float, C.c_float, _P(RtMeshTri), _f32p]),
+    "orc_intersect_plane": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p]),
+    "orc_hit_aabb": (C.c_int, [_f32p, _f32p, _f32p, _f32p, C.c_float, C.c_float]),
+    "orc_reflect": (None, [_f32p, _f32p, _f32p]),
+    "orc_refract": (None, [_f32p, _f32p, C.c_float, _f32p]),
+    "orc_schlick": (C.c_float, [C.c_float, C.c_float]),
+    "orc_color_sky_day": (None, [_f32p, _f32p]),
+    "orc_rotate_about_axis": (None, [_f32p, _f32p, C.c_float, _f32p]),
+    "orc_v3_to_rgba": (None, [_f32p, _P(C.c_uint8)]),
+    "orc_camera_new": (None, [_f32p, _f32p, C.c_float, C.c_float, C.c_float, C.c_float, _P(RtCamera)]),
+    "orc_camera_get_ray": (None, [_P(RtCamera), C.c_float, C.c_float, C.c_float, C.c_float, _f32p, _f32p]),
+    "orc_light_record": (C.c_int, [_P(RtLight), _f32p, _f32p]),
+    "orc_xorshift_from_seed": (None, [_P(C.c_uint8), _P(C.c_uint32), C.c_int]),
+    "orc_xorshift_seed_from_u64": (None, [C.c_uint64, _P(C.c_uint32), C.c_int]),
+    "orc_u32_to_f32": (C.c_float, [C.c_uint32]),
+    "orc_philox4x32_10": (None, [_P(C.c_uint32), _P(C.c_uint32), _P(C.c_uint32)]),
+    "orc_counter_rng_f32": (C.c_float, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                        C.c_uint32]),
+}
+
+_lib = None
+
+
+def build():
+    subprocess.run(["make", "-C", ORACLE_DIR, "--no-print-directory"], check=True, capture_output=True)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(ORACLE_LIB):
+            build()
+        _lib = C.CDLL(ORACLE_LIB)
+        for name, (res, args) in _PROTOS.items():
+            fn = getattr(_lib, name)
+            fn.restype, fn.argtypes = res, args
+    return _lib
+
+
+def f3(v):
+    return (C.c_float * 3)(float(v[0]), float(v[1]), float(v[2]))
+
+
+class OracleError(RuntimeError):
+    pass
+
+
+class OracleScene:
+    """Scene::new + add_* + build_bvh on the CPU oracle, from the same POD
+    description the product consumes."""
+
+    def __init__(self, builder):
+        self._builder = builder
+        self._lib = lib()
+        self._h = self._lib.orc_scene_create(builder.desc())
+        if not self._h:
+            raise OracleError(self._lib.orc_last_error().decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.orc_scene_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _check(self, rc):
+        if rc < 0:
+            raise OracleError(f"[{rc}] " + self._lib.orc_last_error().decode())
+
+    def render_chunk(self, settings, chunk, rng_mode=ORC_RNG_COUNTER, seed=12345, sum_segment=0, stats=False):
+        h, w = chunk.height, chunk.width
+        rgb = np.empty((h, w, 3), dtype=np.float32)
+        rgba = np.empty((h, w, 4), dtype=np.uint8)
+        cn = OrcCounters()
+        self._check(self._lib.orc_render_chunk(self._h, C.byref(settings.c), C.byref(chunk), rng_mode, seed,
+                                               sum_segment, 1 if stats else 0, rgb.ctypes.data, rgba.ctypes.data,
+                                               C.byref(cn)))
+        return rgb, rgba, cn
+
+    def accumulate_chunk(self, settings, chunk, seed, sample_first, sample_count):
+        acc = np.empty((chunk.height, chunk.width, 3), dtype=np.float32)
+        self._check(self._lib.orc_accumulate_chunk(self._h, C.byref(settings.c), C.byref(chunk), seed, sample_first,
+                                                   sample_count, acc.ctypes.data))
+        return acc
+
+    def render_image_mt(self, settings, count, threads, rng_mode=ORC_RNG_XORSHIFT_CHUNK, seed=12345):
+        h, w = settings.height, settings.width
+        rgb = np.empty((h, w, 3), dtype=np.float32)
+        rgba = np.empty((h, w, 4), dtype=np.uint8)
+        cn = OrcCounters()
+        ms = C.c_double()
+        self._check(self._lib.orc_render_image_mt(self._h, C.byref(settings.c), count[0], count[1], threads, rng_mode,
+                                                  seed, rgb.ctypes.data, rgba.ctypes.data, C.byref(cn), C.byref(ms)))
+        return rgb, rgba, cn, ms.value
+
+    def render_chunks_mt(self, settings, count, chunk_first, chunk_count, threads, rng_mode=ORC_RNG_XORSHIFT_CHUNK,
+                         seed=12345, stats=False):
+        cn = OrcCounters()
+        ms = C.c_double()
+        self._check(self._lib.orc_render_chunks_mt(self._h, C.byref(settings.c), count[0], count[1], chunk_first,
+                                                   chunk_count, threads, rng_mode, seed, 1 if stats else 0,
+                                                   C.byref(cn), C.byref(ms)))
+        return cn, ms.value
+
+    def primary_hits(self, settings, chunk):
+        h, w = chunk.height, chunk.width
+        t = np.empty((h, w), dtype=np.float32)
+        n = np.empty((h, w, 3), dtype=np.float32)
+        e = np.empty((h, w), dtype=np.int32)
+        tri = np.empty((h, w), dtype=np.int32)
+        self._check(self._lib.orc_primary_hits(self._h, C.byref(settings.c), C.byref(chunk), t.ctypes.data,
+                                               n.ctypes.data, e.ctypes.data, tri.ctypes.data))
+        return t, n, e, tri
+
+    def bvh_order(self, mesh_index=-1):
+        n = self._lib.orc_scene_bvh_order(self._h, mesh_index, None, 0)
+        out = np.zeros(n, dtype=np.uint32)
+        self._lib.orc_scene_bvh_order(self._h, mesh_index, out.ctypes.data, n)
+        return out
+
+    def bvh_depth(self, mesh_index=-1):
+        return self._lib.orc_scene_bvh_depth(self._h, mesh_index)
