@@ -1,0 +1,1001 @@
+// render.hip - the MI355X (gfx950) render core and its C ABI (include/rt_hip.h).
+//
+// Replaces, for one RenderChunk at a time, the pixel loop of the reference's
+// worker thread (src/render.rs:148-159) and everything it calls in
+// raytracer-impl (implementation.rs:498-661, bvh.rs, shapes/*, materials.rs,
+// lights.rs, texture.rs).  Written for CDNA4 only:
+//   * one lane = one work item (a pixel x a segment of its samples), executed by
+//     a per-lane STATE MACHINE whose only heavy loop is one shared two-level BVH
+//     traversal: primary, reflection/refraction and shadow rays of different
+//     lanes all run through the same traversal code, so a 64-lane wave does not
+//     idle while a few lanes chase secondary rays;
+//   * the recursion of cast_ray_recursive (implementation.rs:559-633) is turned
+//     into a weight-carrying work list (the colour is linear in the children),
+//     with the reference's depth-budget split; deferred rays live in a small
+//     per-lane private stack, the traversal stack lives in LDS (one dword column
+//     per lane: bank = lane, conflict free);
+//   * two-box 64-byte nodes, near child first, t_max shrinking; exact ties in t
+//     are broken by the reference's visit rank, so the winner is the reference's;
+//   * f32 arithmetic in the reference's operation order, no FMA contraction
+//     (build: -ffp-contract=off), IEEE divide/sqrt; sin/cos of entity rotations
+//     and the camera basis come precomputed from the host;
+//   * counter-based RNG (Philox4x32-10) addressed by (seed, x, y, sample, node):
+//     the image is independent of chunking, launch shape and GPU count.
+// MFMA is deliberately unused: nothing here is a dense contraction.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_hip.h"
+#include "device_scene.h"
+#include "scene_build.h"
+
+// Samples of one pixel are summed sequentially inside segments of this many
+// consecutive sample indices, and the segment sums sequentially in index order.
+// (implementation.rs:641-659 sums all samples sequentially; for spp <= 32 the
+// two are the same order.)  Fixed so that results do not depend on launch shape.
+#define RT_SAMPLE_SEGMENT 32u
+#define RT_BLOCK 256
+#define RT_PENDING_MAX 8
+#define RT_MAX_REFLECTIONS 31u
+
+namespace {
+
+// ===========================================================================
+// device math: f32, reference operation order (types.rs:11-207)
+// ===========================================================================
+struct F3 { float x, y, z; };
+
+__device__ __forceinline__ F3 f3(float x, float y, float z) { return F3{x, y, z}; }
+__device__ __forceinline__ F3 operator+(F3 a, F3 b) { return f3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ F3 operator-(F3 a, F3 b) { return f3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ F3 operator*(F3 a, F3 b) { return f3(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ F3 operator*(F3 a, float f) { return f3(a.x * f, a.y * f, a.z * f); }
+__device__ __forceinline__ F3 operator/(F3 a, float f) { return f3(a.x / f, a.y / f, a.z / f); }
+__device__ __forceinline__ F3 operator-(F3 a) { return f3(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ float dot(F3 a, F3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ F3 cross(F3 a, F3 b) {
+    return f3((a.y * b.z - a.z * b.y), -(a.x * b.z - a.z * b.x), (a.x * b.y - a.y * b.x));
+}
+__device__ __forceinline__ float length(F3 a) { return sqrtf((a.x * a.x) + (a.y * a.y) + (a.z * a.z)); }
+__device__ __forceinline__ F3 unit(F3 a) { float len = length(a); return len == 0.0f ? a : a / len; }
+__device__ __forceinline__ bool is_zero(F3 a) { return a.x == 0.0f && a.y == 0.0f && a.z == 0.0f; }
+// types.rs:200 with cos/sin already evaluated
+__device__ __forceinline__ F3 rotate_cs(F3 p, F3 axis, float c, float s) {
+    return (p * c) + (cross(axis, p) * s) + (axis * dot(axis, p) * (1.0f - c));
+}
+__device__ __forceinline__ F3 ld3(const float* p) { return f3(p[0], p[1], p[2]); }
+__device__ __forceinline__ F3 w3(const Word4& w) { return f3(w.f[0], w.f[1], w.f[2]); }
+
+__device__ __forceinline__ Word4 ldw(const Word4* p) {
+    // one 16-byte load
+    const float4 v = *reinterpret_cast<const float4*>(p);
+    Word4 w; w.f[0] = v.x; w.f[1] = v.y; w.f[2] = v.z; w.f[3] = v.w; return w;
+}
+
+#define RT_PI 3.14159265358979323846f
+#define RT_BIAS 0.004f                       /* implementation.rs:498 */
+#define RT_F32_MAX 3.40282347e+38f
+#define RT_NONE 0xFFFFFFFFu
+
+// ===========================================================================
+// counter-based RNG: Philox4x32-10 (Random123), counter = (x | y<<16, sample,
+// node, purpose | block<<8), key = seed.  f32 = (u >> 8) * 2^-24 like rand 0.9.
+// ===========================================================================
+enum { PURPOSE_LENS = 0, PURPOSE_PATH = 1 };
+
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __forceinline__ float u32_to_f32(uint32_t v) { return (float)(v >> 8) * (1.0f / 16777216.0f); }
+
+// the two draws every consumer on this path needs (lens jitter: implementation.rs:649-650;
+// random_normal_reflection_angle: :17-18)
+__device__ __forceinline__ void rng_pair(uint64_t seed, uint32_t px, uint32_t py, uint32_t sample, uint32_t node, uint32_t purpose, float& r0, float& r1) {
+    uint32_t o[4];
+    philox4x32_10(px | (py << 16), sample, node, purpose, (uint32_t)seed, (uint32_t)(seed >> 32), o);
+    r0 = u32_to_f32(o[0]); r1 = u32_to_f32(o[1]);
+}
+
+// ===========================================================================
+// traversal
+// ===========================================================================
+struct Hit {
+    float t;
+    uint32_t ent;      // entity position (TLAS leaf order), RT_NONE = miss
+    uint32_t tri;      // triangle position (global tri arrays), RT_NONE for sphere/plane
+    uint32_t erank;    // reference visit rank of the entity (tie breaking)
+};
+
+// implementation.rs:92-118 for one box; `entry` = the updated t_min.  The
+// per-axis early exit of the reference is equivalent to testing once at the end
+// (t_min only grows, t_max only shrinks, NaN never enters either).
+__device__ __forceinline__ bool slab(float lox, float loy, float loz, float hix, float hiy, float hiz,
+                                     F3 o, F3 inv, float t_min, float t_max, float& entry) {
+    float t0 = (lox - o.x) * inv.x, t1 = (hix - o.x) * inv.x;
+    if (inv.x < 0.0f) { const float s = t0; t0 = t1; t1 = s; }
+    t_min = t0 > t_min ? t0 : t_min; t_max = t1 < t_max ? t1 : t_max;
+    t0 = (loy - o.y) * inv.y; t1 = (hiy - o.y) * inv.y;
+    if (inv.y < 0.0f) { const float s = t0; t0 = t1; t1 = s; }
+    t_min = t0 > t_min ? t0 : t_min; t_max = t1 < t_max ? t1 : t_max;
+    t0 = (loz - o.z) * inv.z; t1 = (hiz - o.z) * inv.z;
+    if (inv.z < 0.0f) { const float s = t0; t0 = t1; t1 = s; }
+    t_min = t0 > t_min ? t0 : t_min; t_max = t1 < t_max ? t1 : t_max;
+    entry = t_min;
+    return !(t_max < t_min);
+}
+
+// Entity::hit's world -> entity ray transform, implementation.rs:288-294
+__device__ __forceinline__ void ray_to_entity(const DevSceneView& S, const Word4& e0, const Word4& e1, F3& o, F3& d) {
+    const uint32_t packed = e1.u[0];
+    const uint32_t n_trans = (packed >> 8) & 0xff, n_rot = (packed >> 16) & 0xff;
+    if (n_trans == 1 && n_rot == 0) { o = o - w3(e0); return; }     // translation kept inline
+    const Word4* x = S.xforms + e1.u[2];
+    for (uint32_t k = 0; k < n_trans; k++) o = o - w3(ldw(x + k));
+    x += n_trans;
+    for (uint32_t k = 0; k < n_rot; k++) {
+        const Word4 a = ldw(x + 2 * k), b = ldw(x + 2 * k + 1);
+        const F3 axis = w3(a);
+        o = rotate_cs(o, axis, a.f[3], b.f[0]);      // cos(-theta), sin(-theta)
+        d = rotate_cs(d, axis, a.f[3], b.f[0]);
+    }
+}
+
+// The shared closest-hit search: Scene::hit_closest (implementation.rs:372-375)
+// = EntityBvhRoot::try_hit (:411-416) over Entity::hit (:285-310) over
+// Sphere::hit / Plane::hit / MeshBvhRoot::try_hit (sphere.rs:36-53, plane.rs:59-90,
+// mesh.rs:92-99).  `stack` is this lane's LDS column (stride RT_BLOCK dwords).
+__device__ __forceinline__ void trace(const DevSceneView& S, const F3 wo, const F3 wd, const float t_min, const float t_max,
+                                      uint32_t* stack, const uint32_t stack_cap, Hit& best) {
+    best.t = t_max; best.ent = RT_NONE; best.tri = RT_NONE; best.erank = 0;
+    float best_t = t_max;                 // culling bound; primitives test against [t_min, t_max]
+
+    const F3 winv = f3(1.0f / wd.x, 1.0f / wd.y, 1.0f / wd.z);
+    F3 o = wo, d = wd, inv = winv;
+    uint32_t sp = 0, inst_sp = 0;
+    bool in_blas = false;
+    const DevNode* nodes = S.nodes;        // current BVH's node base
+    uint32_t tri_base = 0;                 // current BLAS
+    uint32_t cur_ent = 0, cur_erank = 0;
+
+    uint32_t cur;
+    {
+        float e;
+        cur = slab(S.tlas_min[0], S.tlas_min[1], S.tlas_min[2], S.tlas_max[0], S.tlas_max[1], S.tlas_max[2], o, inv, t_min, best_t, e)
+                  ? S.tlas_root_ref : RT_NONE;
+    }
+    for (;;) {
+        if (cur == RT_NONE) {
+            if (in_blas && sp == inst_sp) { in_blas = false; o = wo; d = wd; inv = winv; nodes = S.nodes; }
+            if (sp == 0) break;
+            cur = stack[(--sp) * RT_BLOCK];
+        }
+        if (!(cur & RT_REF_LEAF_BIT)) {
+            // ---- inner node: one 64-byte record, two boxes ------------------
+            const Word4* n = nodes[cur].w;
+            const Word4 a = ldw(n), b = ldw(n + 1), c = ldw(n + 2), r = ldw(n + 3);
+            float el, er;
+            const bool hl = slab(a.f[0], a.f[1], a.f[2], a.f[3], b.f[0], b.f[1], o, inv, t_min, best_t, el);
+            const bool hr = slab(b.f[2], b.f[3], c.f[0], c.f[1], c.f[2], c.f[3], o, inv, t_min, best_t, er);
+            if (hl && hr) {
+                const bool left_first = el <= er;
+                const uint32_t far_ref = left_first ? r.u[1] : r.u[0];
+                cur = left_first ? r.u[0] : r.u[1];
+                if (sp < stack_cap) stack[(sp++) * RT_BLOCK] = far_ref;
+            } else cur = hl ? r.u[0] : (hr ? r.u[1] : RT_NONE);
+            continue;
+        }
+        // ---- leaf -------------------------------------------------------------
+        const uint32_t first = cur & RT_REF_FIRST_MASK;
+        const uint32_t count = ((cur >> RT_REF_COUNT_SHIFT) & 7u) + 1u;
+        cur = RT_NONE;
+        if (in_blas) {
+            // try_hit_tri, mesh.rs:18-76 (normal precomputed with the same ops)
+            for (uint32_t k = 0; k < count; k++) {
+                const uint32_t ti = tri_base + first + k;
+                const Word4* tw = S.tri_hot[ti].w;
+                const Word4 wa = ldw(tw), wb = ldw(tw + 1), wc = ldw(tw + 2);
+                const F3 A = w3(wa), B = w3(wb), C = w3(wc), normal = f3(wa.f[3], wb.f[3], wc.f[3]);
+                const float denominator = dot(d, normal);                       // plane.rs:7-10
+                if (fabsf(denominator) < 1.0e-6f) continue;
+                const float t = dot(A - o, normal) / denominator;               // plane.rs:12-13
+                if (t < t_min || t > t_max) continue;                           // mesh.rs:28
+                if (t > best_t) continue;                                       // cannot win
+                const F3 p = o + (d * t);
+                const F3 n_abp = cross(B - A, p - A);
+                if (dot(normal, n_abp) < 0.0f) continue;
+                const F3 n_bcp = cross(C - B, p - B);
+                if (dot(normal, n_bcp) < 0.0f) continue;
+                const F3 n_cap = cross(A - C, p - C);
+                if (dot(normal, n_cap) < 0.0f) continue;
+                bool better = best.ent == RT_NONE || t < best_t;
+                if (!better && t == best_t) {
+                    // exact tie: the reference keeps the candidate it visits first
+                    // (implementation.rs:415, mesh.rs:96-98); ranks are only fetched here
+                    better = cur_erank < best.erank ||
+                             (cur_erank == best.erank && best.tri != RT_NONE && S.tri_rank[ti] < S.tri_rank[best.tri]);
+                }
+                if (better) { best.t = t; best.ent = cur_ent; best.tri = ti; best.erank = cur_erank; best_t = t; }
+            }
+            continue;
+        }
+        // TLAS leaf: one entity per visit, the rest goes back on the stack
+        if (count > 1 && sp < stack_cap)
+            stack[(sp++) * RT_BLOCK] = RT_REF_LEAF_BIT | ((count - 2) << RT_REF_COUNT_SHIFT) | (first + 1);
+        const Word4* ew = S.entities[first].w;
+        const Word4 e0 = ldw(ew), e1 = ldw(ew + 1), e2 = ldw(ew + 2);
+        const uint32_t kind = e1.u[0] & 0xff;
+        F3 eo = wo, ed = wd;
+        ray_to_entity(S, e0, e1, eo, ed);
+        if (kind == RT_HITABLE_SPHERE) {
+            // intersect_sphere + Sphere::hit, sphere.rs:4-17, 36-39
+            const float radius = e0.f[3];
+            const float qa = dot(ed, ed);
+            const float qb = dot(eo, ed);
+            const float qc = dot(eo, eo) - radius * radius;
+            const float discriminant = qb * qb - qa * qc;
+            if (discriminant > 0.0f) {
+                const float sq = sqrtf(discriminant);
+                const float t0 = (-qb - sq) / qa, t1 = (-qb + sq) / qa;
+                const bool in0 = t_min < t0 && t0 < t_max, in1 = t_min < t1 && t1 < t_max;
+                if (in0 || in1) {
+                    const float t = (in0 && in1) ? fminf(t0, t1) : (in0 ? t0 : t1);
+                    if (best.ent == RT_NONE || t < best_t || (t == best_t && e2.u[3] < best.erank)) {
+                        best.t = t; best.ent = first; best.tri = RT_NONE; best.erank = e2.u[3]; best_t = t;
+                    }
+                }
+            }
+        } else if (kind == RT_HITABLE_PLANE) {
+            // intersect_plane + Plane::hit, plane.rs:4-17, 59-70
+            const Word4* pw = S.planes[e1.u[1]].w;
+            const Word4 p0 = ldw(pw), p1 = ldw(pw + 1);
+            const F3 pn = w3(p0);
+            const float denominator = dot(ed, pn);
+            if (!(fabsf(denominator) < 1.0e-6f)) {
+                const float t = dot(f3(0.0f, 0.0f, 0.0f) - eo, pn) / denominator;
+                if (!(t < t_min || t > t_max)) {
+                    bool ok = true;
+                    if (p1.u[3]) { const F3 p = eo + (ed * t); ok = !(length(p) > p0.f[3]); }
+                    if (ok && (best.ent == RT_NONE || t < best_t || (t == best_t && e2.u[3] < best.erank))) {
+                        best.t = t; best.ent = first; best.tri = RT_NONE; best.erank = e2.u[3]; best_t = t;
+                    }
+                }
+            }
+        } else {
+            // MeshObject::hit -> BLAS (mesh.rs:161-176): enter the instance
+            const Word4* mw = S.meshes[e1.u[1]].w;
+            const Word4 m0 = ldw(mw), m1 = ldw(mw + 1), m2 = ldw(mw + 2);
+            const F3 einv = f3(1.0f / ed.x, 1.0f / ed.y, 1.0f / ed.z);
+            float e;
+            if (slab(m1.f[0], m1.f[1], m1.f[2], m1.f[3], m2.f[0], m2.f[1], eo, einv, t_min, best_t, e)) {
+                in_blas = true; inst_sp = sp;
+                o = eo; d = ed; inv = einv;
+                nodes = S.nodes + m0.u[0]; tri_base = m0.u[1];
+                cur_ent = first; cur_erank = e2.u[3];
+                cur = m0.u[3];
+            }
+        }
+    }
+}
+
+// ===========================================================================
+// hit record (implementation.rs:170-179), rebuilt once for the winning candidate
+// ===========================================================================
+struct HitRec { F3 p, normal; float u, v; uint32_t mat_id, tex_id; int32_t tex_key; int32_t entity_index, tri_index; };
+
+__device__ __forceinline__ void resolve_hit(const DevSceneView& S, F3 o, F3 d, const Hit& h, HitRec& r) {
+    const Word4* ew = S.entities[h.ent].w;
+    const Word4 e0 = ldw(ew), e1 = ldw(ew + 1), e2 = ldw(ew + 2);
+    const uint32_t kind = e1.u[0] & 0xff;
+    ray_to_entity(S, e0, e1, o, d);
+    r.mat_id = e1.u[3]; r.tex_id = e2.u[0]; r.entity_index = (int32_t)e2.u[1]; r.tex_key = -1; r.tri_index = -1;
+    const float t = h.t;
+    F3 p = o + (d * t), normal;
+    r.u = 0.0f; r.v = 0.0f;
+    if (kind == RT_HITABLE_SPHERE) {
+        normal = unit(p / e0.f[3]);                                              // sphere.rs:40-41
+    } else if (kind == RT_HITABLE_PLANE) {
+        const Word4* pw = S.planes[e1.u[1]].w;
+        const Word4 p0 = ldw(pw), p1 = ldw(pw + 1), p2 = ldw(pw + 2);
+        const F3 pn = w3(p0);
+        normal = dot(d, pn) > 0.0f ? -pn : pn;                                   // plane.rs:73
+        r.u = dot(w3(p1), p); r.v = dot(w3(p2), p);                              // plane.rs:75-79
+    } else {
+        const Word4* tw = S.tri_hot[h.tri].w;
+        const Word4 wa = ldw(tw), wb = ldw(tw + 1), wc = ldw(tw + 2);
+        const Word4* cw = S.tri_cold[h.tri].w;
+        const Word4 c0 = ldw(cw), c1 = ldw(cw + 1);
+        const F3 A = w3(wa), B = w3(wb), C = w3(wc), n = f3(wa.f[3], wb.f[3], wc.f[3]);
+        const F3 n_abp = cross(B - A, p - A);
+        const F3 n_cap = cross(A - C, p - C);
+        const float area2 = length(n);                                           // mesh.rs:68-72
+        const float bu = length(n_cap) / area2;
+        const float bv = length(n_abp) / area2;
+        const float bw = 1.0f - bu - bv;
+        r.u = (c0.f[0] * bw + c0.f[2] * bu) + c1.f[0] * bv;
+        r.v = (c0.f[1] * bw + c0.f[3] * bu) + c1.f[1] * bv;
+        normal = unit(n);
+        r.tex_key = c1.i[2]; r.tri_index = c1.i[3];
+    }
+    // implementation.rs:300-306: rotations reversed (+theta), then translations reversed
+    const uint32_t n_trans = (e1.u[0] >> 8) & 0xff, n_rot = (e1.u[0] >> 16) & 0xff;
+    if (n_trans == 1 && n_rot == 0) p = p + w3(e0);
+    else {
+        const Word4* x = S.xforms + e1.u[2];
+        for (uint32_t k = n_rot; k-- > 0;) {
+            const Word4 a = ldw(x + n_trans + 2 * k), b = ldw(x + n_trans + 2 * k + 1);
+            p = rotate_cs(p, w3(a), b.f[1], b.f[2]);
+            normal = rotate_cs(normal, w3(a), b.f[1], b.f[2]);
+        }
+        for (uint32_t k = n_trans; k-- > 0;) p = p + w3(ldw(x + k));
+    }
+    r.p = p; r.normal = normal;
+}
+
+// ===========================================================================
+// shading pieces
+// ===========================================================================
+__device__ __forceinline__ F3 color_sky(const DevSceneView& S, F3 dir) {                // implementation.rs:502-519
+    if (S.sky == RT_SKY_BLACK) return f3(0.0f, 0.0f, 0.0f);
+    const F3 unit_direction = unit(dir);
+    const float t = 0.5f * (unit_direction.y + 1.0f);
+    return f3(1.0f, 1.0f, 1.0f) * (1.0f - t) + (f3(0.5f, 0.7f, 1.0f) * t);
+}
+
+__device__ __forceinline__ uint32_t map_to_rank(float p, uint32_t length) {             // texture.rs:87-91
+    p = fmodf(p, 1.0f);
+    p = p < 0.0f ? 1.0f + p : p;
+    const float v = p * (float)length;
+    if (!(v > 0.0f)) return 0u;
+    if (v >= 4294967040.0f) return 0xFFFFFFFFu;
+    return (uint32_t)v;
+}
+
+// Texture::value, texture.rs:11-134 (chains MeshTextureSet -> MeshTexture -> ColorMap
+// and Checker -> leaf unrolled instead of virtual calls)
+__device__ __forceinline__ F3 texture_value(const DevSceneView& S, uint32_t tex_id, const HitRec& h) {
+    const F3 not_found = f3(1.0f, 0.41f, 0.70f);                                         // texture.rs:124
+    const Word4* tw = S.textures[tex_id].w;
+    Word4 t0 = ldw(tw);
+    uint32_t kind = t0.u[0];
+    if (kind == RT_TEX_MESH_SET) {
+        if (h.tex_key < 0 || h.tex_key >= t0.i[2]) return not_found;
+        tw = S.textures[S.tex_set_entries[t0.i[1] + h.tex_key]].w;
+        t0 = ldw(tw); kind = t0.u[0];
+    }
+    bool mesh = false; F3 ambient = f3(0, 0, 0), diffuse = f3(0, 0, 0);
+    if (kind == RT_TEX_MESH) {
+        diffuse = w3(ldw(tw + 2)); ambient = w3(ldw(tw + 3));
+        if (t0.i[1] < 0) return ambient + diffuse;                                       // texture.rs:111-114
+        mesh = true;
+        tw = S.textures[t0.i[1]].w; t0 = ldw(tw); kind = t0.u[0];
+    }
+    if (kind == RT_TEX_CHECKER) {                                                        // texture.rs:33-44
+        const float size = ldw(tw + 1).f[2];
+        const float sines = sinf(size * h.u) * sinf(size * h.v);
+        tw = S.textures[sines < 0.0f ? t0.i[1] : t0.i[2]].w; t0 = ldw(tw); kind = t0.u[0];
+    }
+    F3 v;
+    if (kind == RT_TEX_COLOR) v = w3(ldw(tw + 2));
+    else if (kind == RT_TEX_UV_TEST) v = f3(h.u, h.v, 1.0f - h.u - h.v);
+    else if (kind == RT_TEX_XYZ_TEST) {
+        const float mx = ldw(tw + 1).f[2];
+        v = f3(0.5f + (h.p.x / mx / 2.0f), 0.5f + (h.p.y / mx / 2.0f), 0.5f + (h.p.z / mx / 2.0f));
+    } else if (kind == RT_TEX_COLOR_MAP) {                                               // texture.rs:93-97
+        const Word4 t1 = ldw(tw + 1);
+        const uint32_t width = t0.u[3], height = t1.u[0];
+        const uint64_t x = map_to_rank(h.u, width), y = map_to_rank(h.v, height);
+        const uint64_t offset = ((uint64_t)height - y) * width + x;      // y <= height: no underflow
+        if (offset < (uint64_t)width * height) { const float* px = S.texels + ((uint64_t)t1.u[1] + offset) * 3; v = f3(px[0], px[1], px[2]); }
+        else v = not_found;
+    } else v = not_found;
+    return mesh ? ambient + (v * diffuse) : v;
+}
+
+struct LightRec { float t; F3 direction, color; float intensity; };
+
+// LightSource::get_direction_and_intensity, lights.rs:35-49, 87-109, 138-148
+__device__ __forceinline__ bool light_record(const DevSceneView& S, uint32_t k, F3 p, LightRec& out) {
+    const Word4* lw = S.lights[k].w;
+    const Word4 l0 = ldw(lw), l1 = ldw(lw + 1), l2 = ldw(lw + 2), l3 = ldw(lw + 3);
+    out.color = w3(l3);
+    if (l0.u[0] == RT_LIGHT_DIRECTIONAL) { out.t = RT_F32_MAX; out.direction = w3(l2); out.intensity = l0.f[1]; return true; }
+    const F3 direction_to_p = p - w3(l1);
+    if (l0.u[0] == RT_LIGHT_LAMP) {
+        const F3 lamp = w3(l2);
+        const float theta = acosf(dot(direction_to_p, lamp) / (length(direction_to_p) * length(lamp)));   // types.rs:71-75
+        const float theta_deg = theta / RT_PI * 180.0f;
+        if (theta_deg > l0.f[2]) return false;
+    }
+    const float t = length(direction_to_p);
+    out.t = t; out.intensity = l0.f[1] / (4.0f * RT_PI * t); out.direction = unit(direction_to_p);
+    return true;
+}
+
+__device__ __forceinline__ F3 reflect(F3 incident_direction, F3 surface_normal) {        // materials.rs:84-87
+    const F3 dir = unit(incident_direction);
+    return dir - (surface_normal * dot(dir, surface_normal) * 2.0f);
+}
+__device__ __forceinline__ F3 refract(F3 v, F3 n, float ni_over_nt) {                    // materials.rs:150-159
+    const F3 uv = unit(v);
+    const float dt = dot(uv, n);
+    const float discriminant = 1.0f - ni_over_nt * ni_over_nt * (1.0f - dt * dt);
+    if (discriminant <= 0.0f) return f3(0.0f, 0.0f, 0.0f);
+    return (uv - (n * dt)) * ni_over_nt - (n * sqrtf(discriminant));
+}
+__device__ __forceinline__ float schlick_reflect_prob(float cosine, float ref_idx) {     // materials.rs:161-165
+    float r0 = (1.0f - ref_idx) / (1.0f + ref_idx);
+    r0 = r0 * r0;
+    return r0 + (1.0f - r0) * powf(1.0f - cosine, 5.0f);
+}
+// implementation.rs:16-36
+__device__ __forceinline__ F3 random_normal_reflection_angle(F3 normal, float r0, float r1) {
+    const float theta1 = r0 * (RT_PI / 2.0f);
+    const float theta2 = r1 * (2.0f * RT_PI);
+    const F3 px = cross(normal, f3(1.0f, 0.0f, 0.0f));
+    const F3 perp = !is_zero(px) ? px : cross(normal, f3(0.0f, 1.0f, 0.0f));
+    const F3 a = rotate_cs(normal, perp, cosf(theta1), sinf(theta1));
+    return rotate_cs(a, normal, cosf(theta2), sinf(theta2));
+}
+
+// Dielectric kr / refraction intensity only (what a shadow ray needs of
+// MatDielectric::scatter, materials.rs:168-190)
+__device__ __forceinline__ float dielectric_kr(F3 dir, F3 normal, float ref_index, float& ni_over_nt, F3& outward_normal) {
+    const float dn = dot(dir, normal);
+    float cosine;
+    if (dn > 0.0f) { outward_normal = -normal; ni_over_nt = ref_index; cosine = ref_index * dn / length(dir); }
+    else { outward_normal = normal; ni_over_nt = 1.0f / ref_index; cosine = -dn / length(dir); }
+    return schlick_reflect_prob(cosine, ref_index);
+}
+
+// ===========================================================================
+// the render kernel
+// ===========================================================================
+struct Pending { F3 o, d, w; uint32_t limit, node; };
+
+struct RenderParams {
+    uint32_t width, height, max_reflections, spp;   // RenderSettings
+    uint32_t left, top, cw, ch;                     // RenderChunk
+    uint64_t seed;
+    uint32_t sample_first, sample_count;            // absolute sample index range to render
+    uint32_t seg_first, seg_count;                  // segments covered by this launch
+    uint32_t tiles_x, pix_slots;                    // 8x8 tiling of the chunk; pix_slots = tiles*64
+    float* partial;                                 // [seg_count][cw*ch][3] segment sums
+    unsigned long long* counters;                   // RtRayCounters on the device (nullable)
+};
+
+__device__ __forceinline__ void gen_camera_ray(const DevSceneView& S, const RenderParams& P, uint32_t px, uint32_t py, float lx, float ly, F3& o, F3& d) {
+    // cast_rays_into_scene :645-646 + Camera::get_ray :482-491
+    const float u = (float)px / (float)P.width;
+    const float v = (float)(P.height - py) / (float)P.height;
+    const float ldx = lx * S.cam_lens_radius, ldy = ly * S.cam_lens_radius;
+    const F3 offset = (ld3(S.cam_u) * ldx) + (ld3(S.cam_v) * ldy);
+    o = ld3(S.cam_origin) + offset;
+    d = ld3(S.cam_llc) + (ld3(S.cam_horizontal) * u) + (ld3(S.cam_vertical) * v) - ld3(S.cam_origin) - offset;
+}
+
+__global__ void __launch_bounds__(RT_BLOCK)
+render_kernel(const DevSceneView S, const RenderParams P) {
+    extern __shared__ uint32_t lds_stack[];
+    uint32_t* stack = lds_stack + threadIdx.x;
+    const uint32_t stack_cap = S.stack_entries;
+
+    const uint64_t total_items = (uint64_t)P.pix_slots * P.seg_count;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint64_t item = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+
+    uint32_t n_primary = 0, n_secondary = 0, n_shadow = 0, n_samples = 0;
+
+    // lane state
+    enum { NEED_ITEM = 0, NEED_SAMPLE = 1, NEED_PATH = 2, PATH_READY = 3, NEED_LIGHT = 4, SHADOW_READY = 5, FINISHED = 6 };
+    int state = NEED_ITEM;
+    uint32_t px = 0, py = 0, s = 0, s_end = 0, out_slot = 0;
+    F3 seg_sum = f3(0, 0, 0), sample_col = f3(0, 0, 0);
+    Pending pend[RT_PENDING_MAX]; uint32_t npend = 0;
+    F3 ro = f3(0, 0, 0), rd = f3(0, 0, 1), rw = f3(0, 0, 0); uint32_t rlimit = 0, rnode = 0;   // current path ray
+    F3 hp = f3(0, 0, 0), hn = f3(0, 0, 0), wa = f3(0, 0, 0), lsum = f3(0, 0, 0);                  // light phase
+    float li = 0.0f;
+    uint32_t light_k = 0;
+    F3 lcol = f3(0, 0, 0), ldir = f3(0, 0, 1); float l_t = 0.0f, closest = 0.0f;
+
+    for (;;) {
+        // ---- cheap transitions until this lane has a ray to trace (or is done) --
+        while (state != PATH_READY && state != SHADOW_READY && state != FINISHED) {
+            if (state == NEED_ITEM) {
+                if (item >= total_items) { state = FINISHED; break; }
+                const uint32_t seg_local = (uint32_t)(item / P.pix_slots), q = (uint32_t)(item % P.pix_slots);
+                item += stride;
+                const uint32_t tile = q >> 6, within = q & 63u;
+                const uint32_t x = (tile % P.tiles_x) * 8u + (within & 7u), y = (tile / P.tiles_x) * 8u + (within >> 3);
+                if (x >= P.cw || y >= P.ch) continue;
+                const uint32_t seg = P.seg_first + seg_local;
+                const uint32_t a = seg * RT_SAMPLE_SEGMENT, b = a + RT_SAMPLE_SEGMENT;
+                const uint32_t r_end = P.sample_first + P.sample_count;
+                s = a > P.sample_first ? a : P.sample_first;
+                s_end = b < r_end ? b : r_end;
+                px = P.left + x; py = P.top + y;
+                out_slot = seg_local * (P.cw * P.ch) + y * P.cw + x;
+                seg_sum = f3(0.0f, 0.0f, 0.0f);
+                state = NEED_SAMPLE;
+            } else if (state == NEED_SAMPLE) {
+                if (s >= s_end) {
+                    float* o = P.partial + (uint64_t)out_slot * 3;
+                    o[0] = seg_sum.x; o[1] = seg_sum.y; o[2] = seg_sum.z;
+                    state = NEED_ITEM; continue;
+                }
+                float lx = 0.0f, ly = 0.0f;
+                if (P.spp > 1) {                                                  // :648-653
+                    float r0, r1; rng_pair(P.seed, px, py, s, 0u, PURPOSE_LENS, r0, r1);
+                    lx = r0 * 2.0f - 1.0f; ly = r1 * 2.0f - 1.0f;
+                }
+                gen_camera_ray(S, P, px, py, lx, ly, ro, rd);
+                rw = f3(1.0f, 1.0f, 1.0f); rlimit = P.max_reflections; rnode = 1u;
+                sample_col = f3(0.0f, 0.0f, 0.0f); npend = 0; n_samples++;
+                if (rlimit == 0) { sample_col = color_sky(S, rd); state = NEED_PATH; }    // :562-564
+                else state = PATH_READY;
+            } else if (state == NEED_PATH) {
+                if (npend == 0) {
+                    // cast_ray's clamp (:635, types.rs:46-50) then col = col + sample (:656)
+                    const F3 c = f3(fmaxf(fminf(sample_col.x, 1.0f), -1.0f), fmaxf(fminf(sample_col.y, 1.0f), -1.0f), fmaxf(fminf(sample_col.z, 1.0f), -1.0f));
+                    seg_sum = seg_sum + c;
+                    s++; state = NEED_SAMPLE; continue;
+                }
+                const Pending& q = pend[--npend];
+                ro = q.o; rd = q.d; rw = q.w; rlimit = q.limit; rnode = q.node;
+                state = PATH_READY;
+            } else {   // NEED_LIGHT: implementation.rs:612-621, one light per shadow ray
+                if (light_k >= S.light_count) {
+                    // (color_from_lights * lights_intensity) * albedo, weighted (:628-630)
+                    sample_col = sample_col + (wa * (lsum * li));
+                    state = NEED_PATH; continue;
+                }
+                LightRec lr;
+                if (!light_record(S, light_k, hp, lr)) { light_k++; continue; }
+                lcol = lr.color * lr.intensity; ldir = lr.direction; l_t = lr.t; closest = RT_BIAS;   // :527-532
+                state = SHADOW_READY;
+            }
+        }
+        if (state == FINISHED) break;        // this lane is done; the wave runs on until all are
+
+        // ---- the one traversal every ray kind shares ------------------------------
+        const bool shadow = state == SHADOW_READY;
+        const F3 to = shadow ? hp : ro;
+        const F3 td = shadow ? -ldir : rd;
+        Hit h;
+        trace(S, to, td, shadow ? closest : RT_BIAS, shadow ? l_t : RT_F32_MAX, stack, stack_cap, h);
+
+        if (shadow) {
+            // cast_light_ray_to_lamp, implementation.rs:535-552
+            n_shadow++;
+            if (h.ent == RT_NONE) {
+                lsum = lsum + (lcol * fmaxf(0.0f, dot(hn, -ldir)));                        // :615-619
+                light_k++; state = NEED_LIGHT; continue;
+            }
+            HitRec hr; resolve_hit(S, to, td, h, hr);
+            const Word4* mw = S.materials[hr.mat_id].w;
+            const Word4 m0 = ldw(mw);
+            bool transparent = false; float refr_intensity = 0.0f;
+            if (m0.u[0] == RT_MAT_DIELECTRIC) {
+                float nint; F3 outn;
+                const float kr = dielectric_kr(td, hr.normal, ldw(mw + 1).f[0], nint, outn);
+                if (!(kr >= 1.0f)) { transparent = true; refr_intensity = (1.0f - kr) * (1.0f - m0.f[3]); }
+            }
+            if (transparent) {
+                const F3 albedo = texture_value(S, hr.tex_id, hr);
+                lcol = lcol * (albedo * refr_intensity);                                  // :541-543
+                closest = h.t + RT_BIAS;
+                state = SHADOW_READY;                                                     // same ray, further on
+            } else { light_k++; state = NEED_LIGHT; }                                     // opaque: ZERO (:548)
+            continue;
+        }
+
+        // ---- path ray: cast_ray_recursive, implementation.rs:566-631 ----------------
+        if (rnode == 1u) n_primary++; else n_secondary++;
+        if (h.ent == RT_NONE) { sample_col = sample_col + (rw * color_sky(S, rd)); state = NEED_PATH; continue; }
+        HitRec hr; resolve_hit(S, ro, rd, h, hr);
+        const Word4* mw = S.materials[hr.mat_id].w;
+        const Word4 m0 = ldw(mw);
+        // Material::scatter
+        bool has_refl = false, has_refr = false; F3 refl_d = f3(0, 0, 0), refr_d = f3(0, 0, 0); float refl_i = 0.0f, refr_i = 0.0f;
+        if (m0.u[0] == RT_MAT_LAMBERTIAN) {                                               // materials.rs:44-53
+            has_refl = true; refl_i = m0.f[1];
+            if (refl_i > 0.0f) {          // the direction is only ever used when the ray is cast (:593)
+                float r0, r1; rng_pair(P.seed, px, py, s, rnode, PURPOSE_PATH, r0, r1);
+                refl_d = random_normal_reflection_angle(hr.normal, r0, r1);
+            }
+        } else if (m0.u[0] == RT_MAT_SPECULAR) {                                          // materials.rs:89-112
+            const F3 reflected = reflect(rd, hr.normal);
+            F3 scattered = reflected;
+            if (m0.f[2] != 0.0f) {
+                float r0, r1; rng_pair(P.seed, px, py, s, rnode, PURPOSE_PATH, r0, r1);
+                scattered = reflected + (unit(random_normal_reflection_angle(hr.normal, r0, r1)) * m0.f[2]);
+            }
+            if (dot(scattered, hr.normal) > 0.0f) { has_refl = true; refl_d = scattered; refl_i = m0.f[1]; }
+        } else {                                                                          // materials.rs:167-204
+            float ni_over_nt; F3 outward_normal;
+            const float kr = dielectric_kr(rd, hr.normal, ldw(mw + 1).f[0], ni_over_nt, outward_normal);
+            if (!(kr >= 1.0f)) {
+                has_refr = true;
+                refr_d = unit(refract(rd, outward_normal, ni_over_nt));
+                refr_i = (1.0f - kr) * (1.0f - m0.f[3]);
+            }
+            has_refl = true; refl_d = unit(reflect(rd, hr.normal)); refl_i = kr * m0.f[1];
+        }
+        // depth budget split, :577-589
+        const uint32_t rl = rlimit - 1u;
+        uint32_t reflect_limit = 0u, refract_limit = 0u;
+        if (has_refl && has_refr) { reflect_limit = rl / 2u; refract_limit = rl - reflect_limit; }
+        else if (has_refl) reflect_limit = rl;
+        else if (has_refr) refract_limit = rl;
+        const bool cast_refl = has_refl && refl_i > 0.0f, cast_refr = has_refr && refr_i > 0.0f;   // :593, :601
+        const float reflection_intensity = cast_refl ? refl_i : 0.0f, refraction_intensity = cast_refr ? refr_i : 0.0f;
+        const F3 albedo = texture_value(S, hr.tex_id, hr);                                // :626
+        wa = rw * albedo;
+        li = fmaxf(0.0f, 1.0f - (reflection_intensity + refraction_intensity));           // :625
+        // children: colour is linear in them, so they carry weight w*albedo*intensity.
+        // Refraction is deferred first so that reflection is evaluated first (:592-605).
+        if (cast_refr) {
+            const F3 cw_ = wa * refraction_intensity;
+            if (refract_limit == 0u) sample_col = sample_col + (cw_ * color_sky(S, refr_d));       // :562-564
+            else if (npend < RT_PENDING_MAX) { Pending& q = pend[npend++]; q.o = hr.p; q.d = refr_d; q.w = cw_; q.limit = refract_limit; q.node = rnode * 2u + 1u; }
+        }
+        if (cast_refl) {
+            const F3 cw_ = wa * reflection_intensity;
+            if (reflect_limit == 0u) sample_col = sample_col + (cw_ * color_sky(S, refl_d));
+            else if (npend < RT_PENDING_MAX) { Pending& q = pend[npend++]; q.o = hr.p; q.d = refl_d; q.w = cw_; q.limit = reflect_limit; q.node = rnode * 2u; }
+        }
+        // lights, :608-621
+        hp = hr.p + (hr.normal * RT_BIAS); hn = hr.normal;
+        lsum = f3(0.0f, 0.0f, 0.0f); light_k = 0u;
+        state = NEED_LIGHT;
+    }
+
+    // ---- ray counters: wave reduce, one atomic per wave and class ------------------
+    if (P.counters) {
+        uint32_t v[4] = {n_primary, n_secondary, n_shadow, n_samples};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            uint32_t x = v[k];
+            for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+            if ((threadIdx.x & 63) == 0 && x) atomicAdd(P.counters + k, (unsigned long long)x);
+        }
+    }
+}
+
+// Folds segment sums into the accumulator in segment order:
+// acc = (first ? 0 : acc) + seg0 + seg1 + ...   (sequential, implementation.rs:656)
+__global__ void fold_kernel(const float* partial, uint32_t seg_count, uint32_t npix, float* acc, uint32_t acc_pitch, uint32_t cw,
+                            uint32_t acc_x, uint32_t acc_y, int init_zero) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    const uint32_t x = i % cw, y = i / cw;
+    float* a = acc + ((uint64_t)(acc_y + y) * acc_pitch + acc_x + x) * 3;
+    float r = init_zero ? 0.0f : a[0], g = init_zero ? 0.0f : a[1], b = init_zero ? 0.0f : a[2];
+    for (uint32_t s = 0; s < seg_count; s++) {
+        const float* p = partial + ((uint64_t)s * npix + i) * 3;
+        r = r + p[0]; g = g + p[1]; b = b + p[2];
+    }
+    a[0] = r; a[1] = g; a[2] = b;
+}
+
+__device__ __forceinline__ uint8_t f32_as_u8(float f) {      // Rust `as u8`: truncate, saturate, NaN -> 0
+    if (!(f > 0.0f)) return 0;
+    if (f >= 255.0f) return 255;
+    return (uint8_t)f;
+}
+
+// col / spp (implementation.rs:659) and v3_to_rgba (src/rgba.rs:6-12).
+// Source: acc image (pitch src_pitch, origin sx,sy); destination images (pitch dst_pitch, origin dx,dy).
+__global__ void finish_kernel(const float* acc, uint32_t src_pitch, uint32_t sx, uint32_t sy, uint32_t cw, uint32_t npix, float spp,
+                              float* rgb, uint8_t* rgba, uint32_t dst_pitch, uint32_t dx, uint32_t dy) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    const uint32_t x = i % cw, y = i / cw;
+    const float* a = acc + ((uint64_t)(sy + y) * src_pitch + sx + x) * 3;
+    const float r = a[0] / spp, g = a[1] / spp, b = a[2] / spp;
+    const uint64_t o = (uint64_t)(dy + y) * dst_pitch + dx + x;
+    if (rgb) { rgb[o * 3] = r; rgb[o * 3 + 1] = g; rgb[o * 3 + 2] = b; }
+    if (rgba) { rgba[o * 4] = f32_as_u8(255.0f * r); rgba[o * 4 + 1] = f32_as_u8(255.0f * g); rgba[o * 4 + 2] = f32_as_u8(255.0f * b); rgba[o * 4 + 3] = 255; }
+}
+
+// First hit_closest of the lens-centre ray of each pixel (parity gate 1).
+__global__ void __launch_bounds__(RT_BLOCK)
+primary_kernel(const DevSceneView S, const RenderParams P, float* t_out, float* n_out, int32_t* e_out, int32_t* tri_out) {
+    extern __shared__ uint32_t lds_stack[];
+    uint32_t* stack = lds_stack + threadIdx.x;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.cw * P.ch) return;
+    const uint32_t x = i % P.cw, y = i / P.cw;
+    F3 o, d;
+    gen_camera_ray(S, P, P.left + x, P.top + y, 0.0f, 0.0f, o, d);
+    Hit h;
+    trace(S, o, d, RT_BIAS, RT_F32_MAX, stack, S.stack_entries, h);
+    float t = -1.0f; F3 n = f3(0, 0, 0); int32_t e = -1, tri = -1;
+    if (h.ent != RT_NONE) { HitRec hr; resolve_hit(S, o, d, h, hr); t = h.t; n = hr.normal; e = hr.entity_index; tri = hr.tri_index; }
+    if (t_out) t_out[i] = t;
+    if (n_out) { n_out[i * 3] = n.x; n_out[i * 3 + 1] = n.y; n_out[i * 3 + 2] = n.z; }
+    if (e_out) e_out[i] = e;
+    if (tri_out) tri_out[i] = tri;
+}
+
+// ===========================================================================
+// host side
+// ===========================================================================
+thread_local std::string g_error;
+
+int set_error(int code, const std::string& msg) { g_error = msg; return code; }
+
+#define HIP_TRY(expr)                                                                                      \
+    do {                                                                                                   \
+        hipError_t _e = (expr);                                                                            \
+        if (_e != hipSuccess) return set_error(RT_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+struct DeviceBuffer {
+    void* p = nullptr; size_t bytes = 0;
+    int ensure(size_t n) {
+        if (n <= bytes) return RT_OK;
+        if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+        HIP_TRY(hipMalloc(&p, n));
+        bytes = n; return RT_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+};
+
+}  // namespace
+
+struct RtScene {
+    int device = 0;
+    DevSceneView view{};
+    RtSceneInfo info{};
+    std::vector<uint32_t> tlas_order;
+    std::vector<std::vector<uint32_t>> blas_order;
+    std::vector<void*> allocations;
+    std::mutex lock;                 // serialises calls per scene
+    hipStream_t stream = nullptr;    // used by the host-pointer entry points
+    DeviceBuffer partial, accum, out_rgb, out_rgba, ctrl, prim;
+    int grid_blocks = 0;
+    size_t lds_bytes = 0;
+};
+
+namespace {
+
+template <class T>
+int upload(RtScene* s, const std::vector<T>& v, const T** dst) {
+    void* p = nullptr;
+    const size_t bytes = v.size() * sizeof(T);
+    HIP_TRY(hipMalloc(&p, bytes ? bytes : 16));
+    s->allocations.push_back(p);
+    if (bytes) HIP_TRY(hipMemcpy(p, v.data(), bytes, hipMemcpyHostToDevice));
+    *dst = reinterpret_cast<const T*>(p);
+    s->info.device_bytes += bytes;
+    return RT_OK;
+}
+
+int validate_call(const RtScene* scene, const RtSettings* st, const RtRenderChunk* ch) {
+    if (!scene || !st || !ch) return set_error(RT_E_INVALID, "null argument");
+    if (st->width == 0 || st->height == 0 || st->samples_per_pixel == 0) return set_error(RT_E_INVALID, "RenderSettings: width, height and samples_per_pixel must be > 0");
+    if (st->width > 65535 || st->height > 65535) return set_error(RT_E_LIMIT, "RenderSettings: image sides are limited to 65535 (RNG counter packs x | y<<16)");
+    if (st->max_reflections > RT_MAX_REFLECTIONS) return set_error(RT_E_LIMIT, "RenderSettings: max_reflections is limited to 31 (recursion-tree node id is 32 bit)");
+    if (ch->width == 0 || ch->height == 0) return set_error(RT_E_INVALID, "RenderChunk: empty chunk");
+    if ((uint64_t)ch->left + ch->width > st->width || (uint64_t)ch->top + ch->height > st->height) return set_error(RT_E_INVALID, "RenderChunk: outside the image");
+    return RT_OK;
+}
+
+// Enqueue: accumulate the sum of clamped samples [first, first+count) of the chunk
+// into `acc` (float3 image with pitch acc_pitch, chunk origin at acc_x/acc_y).
+int enqueue_accumulate(RtScene* scene, const RtSettings* st, const RtRenderChunk* ch, uint64_t seed, uint32_t sample_first,
+                       uint32_t sample_count, float* acc, uint32_t acc_pitch, uint32_t acc_x, uint32_t acc_y, bool init_zero,
+                       unsigned long long* counters_dev, hipStream_t stream) {
+    if (sample_count == 0 || (uint64_t)sample_first + sample_count > st->samples_per_pixel) return set_error(RT_E_INVALID, "sample range outside samples_per_pixel");
+    const uint32_t npix = ch->width * ch->height;
+    const uint32_t seg_lo = sample_first / RT_SAMPLE_SEGMENT;
+    const uint32_t seg_hi = (sample_first + sample_count - 1) / RT_SAMPLE_SEGMENT;     // inclusive
+    const uint32_t nseg = seg_hi - seg_lo + 1;
+    // segment sums of one launch: keep the scratch below ~1 GiB
+    uint32_t batch = (uint32_t)((1ull << 30) / ((uint64_t)npix * 12ull));
+    if (batch == 0) batch = 1;
+    if (batch > nseg) batch = nseg;
+    int rc = scene->partial.ensure((size_t)batch * npix * 12);
+    if (rc) return rc;
+
+    RenderParams P{};
+    P.width = st->width; P.height = st->height; P.max_reflections = st->max_reflections; P.spp = st->samples_per_pixel;
+    P.left = ch->left; P.top = ch->top; P.cw = ch->width; P.ch = ch->height;
+    P.seed = seed; P.sample_first = sample_first; P.sample_count = sample_count;
+    P.tiles_x = (ch->width + 7) / 8;
+    P.pix_slots = P.tiles_x * ((ch->height + 7) / 8) * 64;
+    P.partial = (float*)scene->partial.p;
+    P.counters = counters_dev;
+    for (uint32_t b0 = 0; b0 < nseg; b0 += batch) {
+        const uint32_t bn = (nseg - b0 < batch) ? nseg - b0 : batch;
+        P.seg_first = seg_lo + b0; P.seg_count = bn;
+        const uint64_t items = (uint64_t)P.pix_slots * bn;
+        uint64_t blocks = (items + RT_BLOCK - 1) / RT_BLOCK;
+        if (blocks > (uint64_t)scene->grid_blocks) blocks = scene->grid_blocks;
+        hipLaunchKernelGGL(render_kernel, dim3((uint32_t)blocks), dim3(RT_BLOCK), scene->lds_bytes, stream, scene->view, P);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(fold_kernel, dim3((npix + 255) / 256), dim3(256), 0, stream, (const float*)scene->partial.p, bn, npix, acc, acc_pitch,
+                           ch->width, acc_x, acc_y, (init_zero && b0 == 0) ? 1 : 0);
+        HIP_TRY(hipGetLastError());
+    }
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rt_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* rt_last_error(void) { return g_error.c_str(); }
+
+RtScene* rt_scene_create(const RtSceneDesc* desc, int device) {
+    FlatScene flat; std::string err;
+    int rc = build_flat_scene(desc, flat, err);
+    if (rc) { set_error(rc, err); return nullptr; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { set_error(RT_E_NO_DEVICE, "no HIP device visible"); return nullptr; }
+    if (device < 0 || device >= ndev) { set_error(RT_E_INVALID, "device index out of range"); return nullptr; }
+    RtScene* s = new RtScene();
+    s->device = device;
+    auto fail = [&](void) -> RtScene* { rt_scene_destroy(s); return nullptr; };
+    if (hipSetDevice(device) != hipSuccess) { set_error(RT_E_HIP, "hipSetDevice failed"); return fail(); }
+    s->view = flat.view; s->info = flat.info;
+    s->tlas_order = std::move(flat.tlas_order); s->blas_order = std::move(flat.blas_order);
+    if (upload(s, flat.nodes, &s->view.nodes) || upload(s, flat.entities, &s->view.entities) || upload(s, flat.xforms, &s->view.xforms) ||
+        upload(s, flat.meshes, &s->view.meshes) || upload(s, flat.tri_hot, &s->view.tri_hot) || upload(s, flat.tri_cold, &s->view.tri_cold) ||
+        upload(s, flat.tri_rank, &s->view.tri_rank) || upload(s, flat.planes, &s->view.planes) || upload(s, flat.materials, &s->view.materials) ||
+        upload(s, flat.textures, &s->view.textures) || upload(s, flat.tex_set_entries, &s->view.tex_set_entries) ||
+        upload(s, flat.texels, &s->view.texels) || upload(s, flat.lights, &s->view.lights))
+        return fail();
+    if (hipStreamCreate(&s->stream) != hipSuccess) { set_error(RT_E_HIP, "hipStreamCreate failed"); return fail(); }
+    // launch shape: a resident grid (persistent lanes stride over the work items)
+    s->lds_bytes = (size_t)s->view.stack_entries * RT_BLOCK * sizeof(uint32_t);
+    if (s->lds_bytes > 64 * 1024) { set_error(RT_E_DEPTH, "BVH too deep for the LDS traversal stack (more than 64 levels)"); return fail(); }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { set_error(RT_E_HIP, "hipGetDeviceProperties failed"); return fail(); }
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_kernel, RT_BLOCK, s->lds_bytes) != hipSuccess || per_cu < 1) per_cu = 1;
+    s->grid_blocks = prop.multiProcessorCount * per_cu;
+    if (s->ctrl.ensure(256)) return fail();
+    return s;
+}
+
+void rt_scene_destroy(RtScene* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    if (s->stream) { (void)hipStreamSynchronize(s->stream); (void)hipStreamDestroy(s->stream); }
+    for (void* p : s->allocations) (void)hipFree(p);
+    s->partial.release(); s->accum.release(); s->out_rgb.release(); s->out_rgba.release(); s->ctrl.release(); s->prim.release();
+    delete s;
+}
+
+// body of rt_render_chunk_device; the caller holds scene->lock
+static int render_chunk_device_locked(RtScene* scene, const RtSettings* st, const RtRenderChunk* ch, uint64_t seed, void* rgb_dev, void* rgba_dev,
+                                      uint32_t pitch_pixels, uint32_t out_x, uint32_t out_y, void* counters_dev, hipStream_t sm) {
+    if ((uint64_t)out_x + ch->width > pitch_pixels) return set_error(RT_E_INVALID, "output pitch too small for the chunk");
+    HIP_TRY(hipSetDevice(scene->device));
+    const uint32_t npix = ch->width * ch->height;
+    int rc = scene->accum.ensure((size_t)npix * 12);
+    if (rc) return rc;
+    rc = enqueue_accumulate(scene, st, ch, seed, 0, st->samples_per_pixel, (float*)scene->accum.p, ch->width, 0, 0, true,
+                            (unsigned long long*)counters_dev, sm);
+    if (rc) return rc;
+    hipLaunchKernelGGL(finish_kernel, dim3((npix + 255) / 256), dim3(256), 0, sm, (const float*)scene->accum.p, ch->width, 0u, 0u, ch->width, npix,
+                       (float)st->samples_per_pixel, (float*)rgb_dev, (uint8_t*)rgba_dev, pitch_pixels, out_x, out_y);
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+int rt_render_chunk_device(RtScene* scene, const RtSettings* st, const RtRenderChunk* ch, uint64_t seed, void* rgb_dev, void* rgba_dev,
+                           uint32_t pitch_pixels, uint32_t out_x, uint32_t out_y, void* counters_dev, void* stream) {
+    int rc = validate_call(scene, st, ch);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> g(scene->lock);
+    return render_chunk_device_locked(scene, st, ch, seed, rgb_dev, rgba_dev, pitch_pixels, out_x, out_y, counters_dev, (hipStream_t)stream);
+}
+
+int rt_render_chunk(RtScene* scene, const RtSettings* st, const RtRenderChunk* ch, uint64_t seed, float* rgb_out, uint8_t* rgba_out,
+                    RtRayCounters* counters) {
+    int rc = validate_call(scene, st, ch);
+    if (rc) return rc;
+    const size_t npix = (size_t)ch->width * ch->height;
+    std::lock_guard<std::mutex> g(scene->lock);
+    HIP_TRY(hipSetDevice(scene->device));
+    if ((rc = scene->out_rgb.ensure(npix * 12)) || (rc = scene->out_rgba.ensure(npix * 4))) return rc;
+    HIP_TRY(hipMemsetAsync(scene->ctrl.p, 0, sizeof(RtRayCounters), scene->stream));
+    rc = render_chunk_device_locked(scene, st, ch, seed, scene->out_rgb.p, scene->out_rgba.p, ch->width, 0, 0, scene->ctrl.p, scene->stream);
+    if (rc) return rc;
+    RtRayCounters c{};
+    if (rgb_out) HIP_TRY(hipMemcpyAsync(rgb_out, scene->out_rgb.p, npix * 12, hipMemcpyDeviceToHost, scene->stream));
+    if (rgba_out) HIP_TRY(hipMemcpyAsync(rgba_out, scene->out_rgba.p, npix * 4, hipMemcpyDeviceToHost, scene->stream));
+    HIP_TRY(hipMemcpyAsync(&c, scene->ctrl.p, sizeof(c), hipMemcpyDeviceToHost, scene->stream));
+    HIP_TRY(hipStreamSynchronize(scene->stream));
+    if (counters) { counters->primary += c.primary; counters->secondary += c.secondary; counters->shadow += c.shadow; counters->samples += c.samples; }
+    return RT_OK;
+}
+
+int rt_accumulate_chunk_device(RtScene* scene, const RtSettings* st, const RtRenderChunk* ch, uint64_t seed, uint32_t sample_first,
+                               uint32_t sample_count, void* accum_dev, void* counters_dev, void* stream) {
+    int rc = validate_call(scene, st, ch);
+    if (rc) return rc;
+    if (!accum_dev) return set_error(RT_E_INVALID, "null accumulator");
+    std::lock_guard<std::mutex> g(scene->lock);
+    HIP_TRY(hipSetDevice(scene->device));
+    return enqueue_accumulate(scene, st, ch, seed, sample_first, sample_count, (float*)accum_dev, st->width, ch->left, ch->top, false,
+                              (unsigned long long*)counters_dev, (hipStream_t)stream);
+}
+
+int rt_resolve_device(int device, const void* accum_dev, uint64_t n_pixels, uint32_t spp, void* rgb_dev, void* rgba_dev, void* stream) {
+    if (!accum_dev || spp == 0 || n_pixels == 0 || n_pixels > 0xFFFFFFFFull) return set_error(RT_E_INVALID, "rt_resolve_device: bad arguments");
+    HIP_TRY(hipSetDevice(device));
+    const uint32_t n = (uint32_t)n_pixels;
+    hipLaunchKernelGGL(finish_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)accum_dev, n, 0u, 0u, n, n, (float)spp,
+                       (float*)rgb_dev, (uint8_t*)rgba_dev, n, 0u, 0u);
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+int rt_primary_hits(RtScene* scene, const RtSettings* st, const RtRenderChunk* ch, float* t_out, float* normal_out, int32_t* entity_out,
+                    int32_t* tri_out) {
+    int rc = validate_call(scene, st, ch);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> g(scene->lock);
+    HIP_TRY(hipSetDevice(scene->device));
+    const size_t npix = (size_t)ch->width * ch->height;
+    if ((rc = scene->prim.ensure(npix * 24))) return rc;
+    float* d_t = (float*)scene->prim.p; float* d_n = d_t + npix; int32_t* d_e = (int32_t*)(d_n + 3 * npix); int32_t* d_tri = d_e + npix;
+    RenderParams P{};
+    P.width = st->width; P.height = st->height; P.max_reflections = st->max_reflections; P.spp = 1;
+    P.left = ch->left; P.top = ch->top; P.cw = ch->width; P.ch = ch->height;
+    hipLaunchKernelGGL(primary_kernel, dim3((uint32_t)((npix + RT_BLOCK - 1) / RT_BLOCK)), dim3(RT_BLOCK), scene->lds_bytes, scene->stream,
+                       scene->view, P, d_t, d_n, d_e, d_tri);
+    HIP_TRY(hipGetLastError());
+    if (t_out) HIP_TRY(hipMemcpyAsync(t_out, d_t, npix * 4, hipMemcpyDeviceToHost, scene->stream));
+    if (normal_out) HIP_TRY(hipMemcpyAsync(normal_out, d_n, npix * 12, hipMemcpyDeviceToHost, scene->stream));
+    if (entity_out) HIP_TRY(hipMemcpyAsync(entity_out, d_e, npix * 4, hipMemcpyDeviceToHost, scene->stream));
+    if (tri_out) HIP_TRY(hipMemcpyAsync(tri_out, d_tri, npix * 4, hipMemcpyDeviceToHost, scene->stream));
+    HIP_TRY(hipStreamSynchronize(scene->stream));
+    return RT_OK;
+}
+
+int rt_create_render_chunks(uint32_t width, uint32_t height, uint32_t count_x, uint32_t count_y, RtRenderChunk* out, uint32_t capacity) {
+    int rc = host_create_render_chunks(width, height, count_x, count_y, out, capacity);
+    if (rc < 0) set_error(rc, "rt_create_render_chunks: zero count or capacity too small");
+    return rc;
+}
+
+void rt_v3_to_rgba(const float* rgb, uint64_t n_pixels, uint8_t* rgba_out) { host_v3_to_rgba(rgb, n_pixels, rgba_out); }
+
+int rt_scene_info(const RtScene* scene, RtSceneInfo* out) {
+    if (!scene || !out) return set_error(RT_E_INVALID, "null argument");
+    *out = scene->info;
+    return RT_OK;
+}
+
+int64_t rt_scene_bvh_order(const RtScene* scene, int64_t mesh_index, uint32_t* out, uint64_t capacity) {
+    if (!scene || mesh_index >= (int64_t)scene->blas_order.size()) return set_error(RT_E_INVALID, "rt_scene_bvh_order: bad arguments");
+    const std::vector<uint32_t>& o = mesh_index < 0 ? scene->tlas_order : scene->blas_order[mesh_index];
+    if (out) for (size_t i = 0; i < o.size() && i < capacity; i++) out[i] = o[i];
+    return (int64_t)o.size();
+}
+
+}  // extern "C"

@@ -1,0 +1,443 @@
+// scene_build.cpp - rt_scene_create's host half.
+//
+// Replaces Scene::build_bvh (raytracer-impl/src/implementation.rs:377-383,
+// 398-440) and MeshBvhRoot::new (shapes/mesh.rs:84-90, 127-133).  The tree
+// TOPOLOGY and the object order inside it are the reference's, because they
+// decide which candidate wins an exact tie in t:
+//   - bounds + centroids per object       bvh.rs:72-83, implementation.rs:258-283,433-440
+//   - longest centroid axis, mean split   bvh.rs:118-127, 155-163
+//   - two-pointer unstable partition      util.rs:6-28 (incl. its untested last element)
+//   - stop at <= 2 objects / empty side   bvh.rs:149, 169
+// The LAYOUT is new: an index permutation is partitioned in place over SoA
+// centroid arrays, and the result is emitted as 64-byte two-box nodes
+// (device_scene.h) with objects re-ordered into leaf order.
+#include "scene_build.h"
+
+#include <cmath>
+#include <cstring>
+
+namespace {
+
+struct P3 { float x, y, z; };
+struct Box { P3 lo, hi; };
+
+inline P3 p3(const RtV3& v) { return P3{v.x, v.y, v.z}; }
+inline float comp(const P3& p, int axis) { return axis == 0 ? p.x : (axis == 1 ? p.y : p.z); }
+
+inline void grow(Box& b, const P3& v) {
+    b.lo.x = fminf(b.lo.x, v.x); b.lo.y = fminf(b.lo.y, v.y); b.lo.z = fminf(b.lo.z, v.z);
+    b.hi.x = fmaxf(b.hi.x, v.x); b.hi.y = fmaxf(b.hi.y, v.y); b.hi.z = fmaxf(b.hi.z, v.z);
+}
+inline bool box_is_infinite(const Box& b) {
+    const float inf = INFINITY;
+    return b.lo.x == -inf && b.lo.y == -inf && b.lo.z == -inf && b.hi.x == inf && b.hi.y == inf && b.hi.z == inf;
+}
+
+// Rodrigues rotation with the same expression shape as types.rs:200
+inline P3 rotate(const P3& p, const P3& k, float theta) {
+    const float c = cosf(theta), s = sinf(theta);
+    const P3 kxp = {k.y * p.z - k.z * p.y, -(k.x * p.z - k.z * p.x), k.x * p.y - k.y * p.x};
+    const float kd = k.x * p.x + k.y * p.y + k.z * p.z;
+    const float omc = 1.0f - c;
+    return P3{(p.x * c + kxp.x * s) + (k.x * kd) * omc,
+              (p.y * c + kxp.y * s) + (k.y * kd) * omc,
+              (p.z * c + kxp.z * s) + (k.z * kd) * omc};
+}
+
+// ---------------------------------------------------------------------------
+// Binary tree in the reference's shape
+// ---------------------------------------------------------------------------
+struct TreeNode {
+    Box box;
+    uint32_t first, count;   // range of positions (always valid: the objects below this node)
+    int32_t left, right;     // -1 for a leaf
+};
+
+struct Tree {
+    std::vector<TreeNode> nodes;     // node 0 = root
+    std::vector<uint32_t> perm;      // position -> object index (the reference's object_bounds order)
+};
+
+Box range_box(const std::vector<Box>& boxes, const std::vector<uint32_t>& perm, uint32_t first, uint32_t count) {
+    Box b{boxes[perm[first]].lo, boxes[perm[first]].lo};   // bvh.rs:109-116 folds [min,max] of each object in order
+    for (uint32_t i = 0; i < count; i++) { grow(b, boxes[perm[first + i]].lo); grow(b, boxes[perm[first + i]].hi); }
+    return b;
+}
+
+Tree build_tree(const std::vector<Box>& boxes, const std::vector<P3>& centroids) {
+    Tree t;
+    const uint32_t n = (uint32_t)boxes.size();
+    t.perm.resize(n);
+    for (uint32_t i = 0; i < n; i++) t.perm[i] = i;
+    t.nodes.reserve((size_t)n * 2);
+    t.nodes.push_back(TreeNode{range_box(boxes, t.perm, 0, n), 0, n, -1, -1});
+    std::vector<uint32_t> todo{0};
+    while (!todo.empty()) {
+        const uint32_t ni = todo.back(); todo.pop_back();
+        const uint32_t first = t.nodes[ni].first, count = t.nodes[ni].count;
+        if (count <= 2) continue;
+        uint32_t* idx = t.perm.data() + first;
+        // extent of the centroids -> longest axis (note: the comparisons use the signed
+        // extent, only the remembered length is abs'ed - bvh.rs:118-127)
+        Box cb{centroids[idx[0]], centroids[idx[0]]};
+        for (uint32_t i = 1; i < count; i++) grow(cb, centroids[idx[i]]);
+        const P3 ext{cb.hi.x - cb.lo.x, cb.hi.y - cb.lo.y, cb.hi.z - cb.lo.z};
+        int axis = 0; float len = fabsf(ext.x);
+        if (ext.y > len) { axis = 1; len = fabsf(ext.y); }
+        if (ext.z > len) { axis = 2; }
+        // mean of the centroid coordinate, summed in current object order
+        float sum = 0.0f;
+        for (uint32_t i = 0; i < count; i++) sum += comp(centroids[idx[i]], axis);
+        const float split = sum / (float)count;
+        // util.rs:13-27
+        uint32_t i = 0, j = count - 1;
+        while (i < j) {
+            if (comp(centroids[idx[i]], axis) <= split) i++;
+            else { const uint32_t tmp = idx[i]; idx[i] = idx[j]; idx[j] = tmp; j--; }
+        }
+        const uint32_t left_len = i + 1, right_len = count - left_len;
+        if (left_len == 0 || right_len == 0) continue;
+        const int32_t l = (int32_t)t.nodes.size();
+        t.nodes.push_back(TreeNode{range_box(boxes, t.perm, first, left_len), first, left_len, -1, -1});
+        t.nodes.push_back(TreeNode{range_box(boxes, t.perm, first + left_len, right_len), first + left_len, right_len, -1, -1});
+        t.nodes[ni].left = l; t.nodes[ni].right = l + 1;
+        todo.push_back((uint32_t)l); todo.push_back((uint32_t)l + 1);
+    }
+    return t;
+}
+
+// Emission order of bvh.rs:210-236 when every box passes: right child first,
+// objects of a leaf in ascending offset.  Gives positions, in visit order.
+void emission_positions(const Tree& t, std::vector<uint32_t>& out) {
+    std::vector<int32_t> st{0};
+    out.clear(); out.reserve(t.perm.size());
+    while (!st.empty()) {
+        const TreeNode& n = t.nodes[st.back()]; st.pop_back();
+        if (n.left >= 0) { st.push_back(n.left); st.push_back(n.right); }
+        else for (uint32_t k = 0; k < n.count; k++) out.push_back(n.first + k);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Emit 64-byte two-box nodes
+// ---------------------------------------------------------------------------
+struct Emitter {
+    std::vector<DevNode>& nodes;
+    uint32_t base;           // index of this BVH's first node in `nodes`
+    const Tree& t;
+    uint32_t depth = 0;      // max inner nodes on a root-to-leaf path
+
+    static uint32_t leaf_ref(uint32_t first, uint32_t count) {
+        return RT_REF_LEAF_BIT | ((count - 1) << RT_REF_COUNT_SHIFT) | (first & RT_REF_FIRST_MASK);
+    }
+    static void put_boxes(DevNode& d, const Box& l, const Box& r) {
+        d.w[0].f[0] = l.lo.x; d.w[0].f[1] = l.lo.y; d.w[0].f[2] = l.lo.z; d.w[0].f[3] = l.hi.x;
+        d.w[1].f[0] = l.hi.y; d.w[1].f[1] = l.hi.z; d.w[1].f[2] = r.lo.x; d.w[1].f[3] = r.lo.y;
+        d.w[2].f[0] = r.lo.z; d.w[2].f[1] = r.hi.x; d.w[2].f[2] = r.hi.y; d.w[2].f[3] = r.hi.z;
+    }
+    // A leaf of more than RT_LEAF_MAX objects (only when a split left one side
+    // empty, bvh.rs:169) becomes a small subtree whose boxes all equal the leaf's
+    // box: every object is still tested exactly when that box is hit.
+    uint32_t emit_leaf(uint32_t first, uint32_t count, const Box& box, uint32_t level) {
+        if (count <= RT_LEAF_MAX) { if (level > depth) depth = level; return leaf_ref(first, count); }
+        const uint32_t me = (uint32_t)nodes.size(); nodes.emplace_back();
+        const uint32_t half = count / 2;
+        const uint32_t l = emit_leaf(first, half, box, level + 1);
+        const uint32_t r = emit_leaf(first + half, count - half, box, level + 1);
+        DevNode& d = nodes[me];
+        put_boxes(d, box, box); d.w[3].u[0] = l; d.w[3].u[1] = r; d.w[3].u[2] = d.w[3].u[3] = 0;
+        return me - base;
+    }
+    uint32_t emit(int32_t ni, uint32_t level) {
+        const TreeNode n = t.nodes[ni];
+        if (n.left < 0) return emit_leaf(n.first, n.count, n.box, level);
+        const uint32_t me = (uint32_t)nodes.size(); nodes.emplace_back();
+        const uint32_t l = emit(n.left, level + 1);
+        const uint32_t r = emit(n.right, level + 1);
+        DevNode& d = nodes[me];
+        put_boxes(d, t.nodes[n.left].box, t.nodes[n.right].box);
+        d.w[3].u[0] = l; d.w[3].u[1] = r; d.w[3].u[2] = d.w[3].u[3] = 0;
+        return me - base;
+    }
+};
+
+int bad(std::string& err, const std::string& msg) { err = msg; return RT_E_INVALID; }
+
+}  // namespace
+
+int build_flat_scene(const RtSceneDesc* d, FlatScene& out, std::string& err) {
+    if (!d) return bad(err, "rt_scene_create: null description");
+    if (d->abi_version != RT_ABI_VERSION) return bad(err, "rt_scene_create: abi_version mismatch");
+    if (d->entity_count == 0) return bad(err, "rt_scene_create: scene has no entities");
+    if (d->entity_count > RT_REF_FIRST_MASK) { err = "too many entities"; return RT_E_LIMIT; }
+    const uint64_t n_mat = d->material_count, n_tex = d->texture_count;
+
+    // ---- validation ---------------------------------------------------------
+    for (uint64_t i = 0; i < d->texture_count; i++) {
+        const RtTexture& t = d->textures[i];
+        auto child_ok = [&](int32_t c) { return c >= 0 && (uint64_t)c < n_tex; };
+        switch (t.kind) {
+            case RT_TEX_COLOR: case RT_TEX_UV_TEST: case RT_TEX_XYZ_TEST: break;
+            case RT_TEX_CHECKER:
+                if (!child_ok(t.child0) || !child_ok(t.child1)) return bad(err, "checker texture: bad child");
+                for (int32_t c : {t.child0, t.child1}) {
+                    const uint32_t k = d->textures[c].kind;
+                    if (k == RT_TEX_CHECKER || k == RT_TEX_MESH || k == RT_TEX_MESH_SET) return bad(err, "checker texture: children must be leaf textures");
+                }
+                break;
+            case RT_TEX_COLOR_MAP:
+                if (t.width == 0 || t.height == 0 || t.texel_first + (uint64_t)t.width * t.height > d->texel_count) return bad(err, "color map: texels out of range");
+                break;
+            case RT_TEX_MESH:
+                if (t.child0 != -1 && (!child_ok(t.child0) || d->textures[t.child0].kind != RT_TEX_COLOR_MAP)) return bad(err, "mesh texture: map must be a color map");
+                break;
+            case RT_TEX_MESH_SET:
+                if (t.child0 < 0 || t.child1 < 0 || (uint64_t)t.child0 + (uint64_t)t.child1 > d->tex_set_entry_count) return bad(err, "mesh texture set: entries out of range");
+                for (int32_t k = 0; k < t.child1; k++) {
+                    const int32_t e = d->tex_set_entries[t.child0 + k];
+                    if (!child_ok(e) || d->textures[e].kind != RT_TEX_MESH) return bad(err, "mesh texture set: entries must be mesh textures");
+                }
+                break;
+            default: return bad(err, "unknown texture kind");
+        }
+    }
+    for (uint64_t i = 0; i < n_mat; i++) if (d->materials[i].kind > RT_MAT_DIELECTRIC) return bad(err, "unknown material kind");
+    for (uint64_t i = 0; i < d->light_count; i++) if (d->lights[i].kind > RT_LIGHT_DIRECTIONAL) return bad(err, "unknown light kind");
+    if (d->sky > RT_SKY_BLACK) return bad(err, "unknown sky");
+    for (uint64_t i = 0; i < d->sphere_count; i++) if (d->spheres[i].mat_id >= n_mat || d->spheres[i].tex_id >= n_tex) return bad(err, "sphere: material/texture id out of range");
+    for (uint64_t i = 0; i < d->plane_count; i++) if (d->planes[i].mat_id >= n_mat || d->planes[i].tex_id >= n_tex) return bad(err, "plane: material/texture id out of range");
+    for (uint64_t i = 0; i < d->mesh_object_count; i++) {
+        const RtMeshObject& m = d->mesh_objects[i];
+        if (m.mesh_index >= d->mesh_count || m.mat_id >= n_mat || m.tex_id >= n_tex) return bad(err, "mesh object: index out of range");
+    }
+    for (uint64_t i = 0; i < d->mesh_count; i++) {
+        if (d->meshes[i].tri_count == 0 || !d->meshes[i].tris) return bad(err, "mesh without triangles");
+        if (d->meshes[i].tri_count > RT_REF_FIRST_MASK) { err = "mesh too large"; return RT_E_LIMIT; }
+    }
+    for (uint64_t i = 0; i < d->entity_count; i++) {
+        const RtEntity& e = d->entities[i];
+        const uint64_t lim = e.hitable_kind == RT_HITABLE_SPHERE ? d->sphere_count : e.hitable_kind == RT_HITABLE_PLANE ? d->plane_count
+                           : e.hitable_kind == RT_HITABLE_MESH ? d->mesh_object_count : 0;
+        if (e.hitable_index >= lim) return bad(err, "entity: hitable out of range");
+        if ((uint64_t)e.translation_first + e.translation_count > d->translation_count) return bad(err, "entity: translations out of range");
+        if ((uint64_t)e.rotation_first + e.rotation_count > d->rotation_count) return bad(err, "entity: rotations out of range");
+        if (e.translation_count > 255 || e.rotation_count > 255) { err = "entity: more than 255 transforms"; return RT_E_LIMIT; }
+    }
+
+    // ---- camera / scalars -----------------------------------------------------
+    DevSceneView& v = out.view;
+    auto put3 = [](float* dst, const RtV3& s) { dst[0] = s.x; dst[1] = s.y; dst[2] = s.z; };
+    put3(v.cam_llc, d->camera.lower_left_corner); put3(v.cam_horizontal, d->camera.horizontal); put3(v.cam_vertical, d->camera.vertical);
+    put3(v.cam_origin, d->camera.origin); put3(v.cam_u, d->camera.u); put3(v.cam_v, d->camera.v);
+    v.cam_lens_radius = d->camera.lens_radius;
+    v.sky = d->sky; v.light_count = (uint32_t)d->light_count; v.entity_count = (uint32_t)d->entity_count;
+
+    // ---- BLAS per mesh (MeshBvhRoot::new) ------------------------------------
+    // TLAS nodes are emitted first so that node 0.. belongs to the TLAS; reserve
+    // by building the BLAS trees now and emitting them after the TLAS.
+    const uint64_t n_mesh = d->mesh_count;
+    std::vector<Tree> blas(n_mesh);
+    std::vector<Box> mesh_root_box(n_mesh);
+    for (uint64_t m = 0; m < n_mesh; m++) {
+        const RtMesh& mesh = d->meshes[m];
+        std::vector<Box> boxes(mesh.tri_count); std::vector<P3> cents(mesh.tri_count);
+        for (uint64_t i = 0; i < mesh.tri_count; i++) {
+            const P3 a = p3(mesh.tris[i].a), b = p3(mesh.tris[i].b), c = p3(mesh.tris[i].c);
+            Box bx{a, a}; grow(bx, b); grow(bx, c);
+            boxes[i] = bx;
+            // (a + b + c) * 0.33333, mesh.rs:130
+            cents[i] = P3{((a.x + b.x) + c.x) * 0.33333f, ((a.y + b.y) + c.y) * 0.33333f, ((a.z + b.z) + c.z) * 0.33333f};
+        }
+        blas[m] = build_tree(boxes, cents);
+        mesh_root_box[m] = blas[m].nodes[0].box;
+    }
+
+    // ---- TLAS over entities (EntityBvhRoot::new) ------------------------------
+    const uint64_t n_ent = d->entity_count;
+    std::vector<Box> ebox(n_ent); std::vector<P3> ecent(n_ent);
+    for (uint64_t i = 0; i < n_ent; i++) {
+        const RtEntity& e = d->entities[i];
+        Box hb;
+        if (e.hitable_kind == RT_HITABLE_SPHERE) { const float r = d->spheres[e.hitable_index].radius; hb = Box{P3{0.0f - r, 0.0f - r, 0.0f - r}, P3{0.0f + r, 0.0f + r, 0.0f + r}}; }
+        else if (e.hitable_kind == RT_HITABLE_PLANE) hb = Box{P3{-INFINITY, -INFINITY, -INFINITY}, P3{INFINITY, INFINITY, INFINITY}};
+        else hb = mesh_root_box[d->mesh_objects[e.hitable_index].mesh_index];
+        // calculate_origin_aabb, implementation.rs:258-283
+        P3 c[8] = {hb.lo, {hb.lo.x, hb.lo.y, hb.hi.z}, {hb.lo.x, hb.hi.y, hb.lo.z}, {hb.hi.x, hb.lo.y, hb.lo.z},
+                   hb.hi, {hb.hi.x, hb.hi.y, hb.lo.z}, {hb.hi.x, hb.lo.y, hb.hi.z}, {hb.lo.x, hb.hi.y, hb.hi.z}};
+        if (!box_is_infinite(hb))
+            for (uint32_t k = e.rotation_count; k-- > 0;) {
+                const RtRotation& r = d->rotations[e.rotation_first + k];
+                for (P3& p : c) p = rotate(p, p3(r.axis), r.theta);
+            }
+        P3 origin{0.0f, 0.0f, 0.0f};
+        for (uint32_t k = 0; k < e.translation_count; k++) {
+            const P3 t = p3(d->translations[e.translation_first + k]);
+            for (P3& p : c) p = P3{p.x + t.x, p.y + t.y, p.z + t.z};
+            origin = P3{origin.x + t.x, origin.y + t.y, origin.z + t.z};
+        }
+        Box bx{c[0], c[0]};
+        for (int k = 1; k < 8; k++) grow(bx, c[k]);
+        ebox[i] = bx;
+        // implementation.rs:437
+        ecent[i] = box_is_infinite(bx) ? origin
+                                       : P3{bx.lo.x * 0.5f + bx.hi.x * 0.5f, bx.lo.y * 0.5f + bx.hi.y * 0.5f, bx.lo.z * 0.5f + bx.hi.z * 0.5f};
+    }
+    Tree tlas = build_tree(ebox, ecent);
+
+    // ---- emit nodes -------------------------------------------------------------
+    out.nodes.clear();
+    Emitter te{out.nodes, 0, tlas};
+    v.tlas_root_ref = te.emit(0, 0);
+    put3(v.tlas_min, RtV3{tlas.nodes[0].box.lo.x, tlas.nodes[0].box.lo.y, tlas.nodes[0].box.lo.z});
+    put3(v.tlas_max, RtV3{tlas.nodes[0].box.hi.x, tlas.nodes[0].box.hi.y, tlas.nodes[0].box.hi.z});
+    out.info.tlas_node_count = out.nodes.size();
+    out.info.tlas_depth = te.depth;
+
+    out.meshes.resize(n_mesh);
+    out.blas_order.resize(n_mesh);
+    uint32_t blas_depth = 0;
+    uint64_t tri_total = 0;
+    std::vector<uint32_t> pos_order;
+    for (uint64_t m = 0; m < n_mesh; m++) {
+        const RtMesh& mesh = d->meshes[m];
+        const Tree& t = blas[m];
+        const uint32_t node_base = (uint32_t)out.nodes.size();
+        const uint32_t tri_base = (uint32_t)out.tri_hot.size();
+        Emitter be{out.nodes, node_base, t};
+        const uint32_t root = be.emit(0, 0);
+        if (be.depth > blas_depth) blas_depth = be.depth;
+        DevMesh& dm = out.meshes[m];
+        dm.w[0].u[0] = node_base; dm.w[0].u[1] = tri_base; dm.w[0].u[2] = (uint32_t)mesh.tri_count; dm.w[0].u[3] = root;
+        const Box& rb = t.nodes[0].box;
+        dm.w[1].f[0] = rb.lo.x; dm.w[1].f[1] = rb.lo.y; dm.w[1].f[2] = rb.lo.z; dm.w[1].f[3] = rb.hi.x;
+        dm.w[2].f[0] = rb.hi.y; dm.w[2].f[1] = rb.hi.z; dm.w[2].f[2] = 0.0f; dm.w[2].f[3] = 0.0f;
+        // triangles in leaf order
+        emission_positions(t, pos_order);
+        std::vector<uint32_t> rank(mesh.tri_count);
+        out.blas_order[m].resize(mesh.tri_count);
+        for (uint32_t k = 0; k < pos_order.size(); k++) { rank[pos_order[k]] = k; out.blas_order[m][k] = t.perm[pos_order[k]]; }
+        for (uint64_t p = 0; p < mesh.tri_count; p++) {
+            const RtMeshTri& tr = mesh.tris[t.perm[p]];
+            // normal = cross(b - a, c - a), mesh.rs:22-24 / types.rs:64-68
+            const P3 ab{tr.b.x - tr.a.x, tr.b.y - tr.a.y, tr.b.z - tr.a.z};
+            const P3 ac{tr.c.x - tr.a.x, tr.c.y - tr.a.y, tr.c.z - tr.a.z};
+            const P3 n{ab.y * ac.z - ab.z * ac.y, -(ab.x * ac.z - ab.z * ac.x), ab.x * ac.y - ab.y * ac.x};
+            DevTriHot h;
+            h.w[0].f[0] = tr.a.x; h.w[0].f[1] = tr.a.y; h.w[0].f[2] = tr.a.z; h.w[0].f[3] = n.x;
+            h.w[1].f[0] = tr.b.x; h.w[1].f[1] = tr.b.y; h.w[1].f[2] = tr.b.z; h.w[1].f[3] = n.y;
+            h.w[2].f[0] = tr.c.x; h.w[2].f[1] = tr.c.y; h.w[2].f[2] = tr.c.z; h.w[2].f[3] = n.z;
+            out.tri_hot.push_back(h);
+            DevTriCold c;
+            c.w[0].f[0] = tr.a_uv.x; c.w[0].f[1] = tr.a_uv.y; c.w[0].f[2] = tr.b_uv.x; c.w[0].f[3] = tr.b_uv.y;
+            c.w[1].f[0] = tr.c_uv.x; c.w[1].f[1] = tr.c_uv.y; c.w[1].i[2] = tr.tex_key; c.w[1].i[3] = (int32_t)t.perm[p];
+            out.tri_cold.push_back(c);
+            out.tri_rank.push_back(rank[p]);
+        }
+        tri_total += mesh.tri_count;
+    }
+    out.info.blas_node_count = out.nodes.size() - out.info.tlas_node_count;
+    out.info.blas_depth = blas_depth;
+    out.info.mesh_count = n_mesh;
+    out.info.triangle_count = tri_total;
+    out.info.entity_count = n_ent;
+
+    // ---- entities in TLAS leaf order ------------------------------------------
+    emission_positions(tlas, pos_order);
+    std::vector<uint32_t> erank(n_ent);
+    out.tlas_order.resize(n_ent);
+    for (uint32_t k = 0; k < pos_order.size(); k++) { erank[pos_order[k]] = k; out.tlas_order[k] = tlas.perm[pos_order[k]]; }
+    out.entities.resize(n_ent);
+    uint64_t inst_tris = 0;
+    for (uint64_t p = 0; p < n_ent; p++) {
+        const uint32_t ei = tlas.perm[p];
+        const RtEntity& e = d->entities[ei];
+        DevEntity& de = out.entities[p];
+        memset(&de, 0, sizeof(de));
+        uint32_t mat = 0, tex = 0, hidx = 0; float radius = 0.0f;
+        if (e.hitable_kind == RT_HITABLE_SPHERE) { const RtSphere& s = d->spheres[e.hitable_index]; mat = s.mat_id; tex = s.tex_id; radius = s.radius; }
+        else if (e.hitable_kind == RT_HITABLE_PLANE) { const RtPlane& s = d->planes[e.hitable_index]; mat = s.mat_id; tex = s.tex_id; hidx = e.hitable_index; }
+        else { const RtMeshObject& s = d->mesh_objects[e.hitable_index]; mat = s.mat_id; tex = s.tex_id; hidx = s.mesh_index; inst_tris += d->meshes[s.mesh_index].tri_count; }
+        if (e.translation_count > 0) { const RtV3& t0 = d->translations[e.translation_first]; de.w[0].f[0] = t0.x; de.w[0].f[1] = t0.y; de.w[0].f[2] = t0.z; }
+        de.w[0].f[3] = radius;
+        de.w[1].u[0] = e.hitable_kind | (e.translation_count << 8) | (e.rotation_count << 16);
+        de.w[1].u[1] = hidx;
+        de.w[1].u[2] = (uint32_t)out.xforms.size();
+        de.w[1].u[3] = mat;
+        de.w[2].u[0] = tex; de.w[2].u[1] = ei; de.w[2].i[2] = e.id; de.w[2].u[3] = erank[p];
+        for (uint32_t k = 0; k < e.translation_count; k++) {
+            const RtV3& t = d->translations[e.translation_first + k];
+            Word4 w; w.f[0] = t.x; w.f[1] = t.y; w.f[2] = t.z; w.f[3] = 0.0f;
+            out.xforms.push_back(w);
+        }
+        for (uint32_t k = 0; k < e.rotation_count; k++) {
+            const RtRotation& r = d->rotations[e.rotation_first + k];
+            Word4 w0, w1;
+            w0.f[0] = r.axis.x; w0.f[1] = r.axis.y; w0.f[2] = r.axis.z; w0.f[3] = cosf(-r.theta);
+            w1.f[0] = sinf(-r.theta); w1.f[1] = cosf(r.theta); w1.f[2] = sinf(r.theta); w1.f[3] = 0.0f;
+            out.xforms.push_back(w0); out.xforms.push_back(w1);
+        }
+    }
+    out.info.instanced_triangle_count = inst_tris;
+    if (out.xforms.empty()) out.xforms.emplace_back();
+
+    // ---- planes / materials / textures / lights ---------------------------------
+    out.planes.resize(d->plane_count ? d->plane_count : 1);
+    for (uint64_t i = 0; i < d->plane_count; i++) {
+        const RtPlane& s = d->planes[i]; DevPlane& p = out.planes[i];
+        p.w[0].f[0] = s.normal.x; p.w[0].f[1] = s.normal.y; p.w[0].f[2] = s.normal.z; p.w[0].f[3] = s.radius;
+        p.w[1].f[0] = s.u_basis.x; p.w[1].f[1] = s.u_basis.y; p.w[1].f[2] = s.u_basis.z; p.w[1].u[3] = s.has_radius ? 1u : 0u;
+        p.w[2].f[0] = s.v_basis.x; p.w[2].f[1] = s.v_basis.y; p.w[2].f[2] = s.v_basis.z; p.w[2].f[3] = 0.0f;
+    }
+    out.materials.resize(n_mat ? n_mat : 1);
+    for (uint64_t i = 0; i < n_mat; i++) {
+        const RtMaterial& s = d->materials[i]; DevMaterial& m = out.materials[i];
+        m.w[0].u[0] = s.kind; m.w[0].f[1] = s.reflectivity; m.w[0].f[2] = s.fuzz; m.w[0].f[3] = s.opacity;
+        m.w[1].f[0] = s.ref_index; m.w[1].f[1] = m.w[1].f[2] = m.w[1].f[3] = 0.0f;
+    }
+    out.textures.resize(n_tex ? n_tex : 1);
+    for (uint64_t i = 0; i < n_tex; i++) {
+        const RtTexture& s = d->textures[i]; DevTexture& t = out.textures[i];
+        if (s.texel_first > 0xFFFFFFFFull / 3) { err = "too many texels"; return RT_E_LIMIT; }
+        t.w[0].u[0] = s.kind; t.w[0].i[1] = s.child0; t.w[0].i[2] = s.child1; t.w[0].u[3] = s.width;
+        t.w[1].u[0] = s.height; t.w[1].u[1] = (uint32_t)s.texel_first; t.w[1].f[2] = s.size; t.w[1].f[3] = 0.0f;
+        t.w[2].f[0] = s.color.x; t.w[2].f[1] = s.color.y; t.w[2].f[2] = s.color.z; t.w[2].f[3] = 0.0f;
+        t.w[3].f[0] = s.color2.x; t.w[3].f[1] = s.color2.y; t.w[3].f[2] = s.color2.z; t.w[3].f[3] = 0.0f;
+    }
+    out.tex_set_entries.assign(d->tex_set_entries, d->tex_set_entries + d->tex_set_entry_count);
+    if (out.tex_set_entries.empty()) out.tex_set_entries.push_back(0);
+    out.texels.resize(d->texel_count ? d->texel_count * 3 : 4);
+    for (uint64_t i = 0; i < d->texel_count; i++) { out.texels[3 * i] = d->texels[i].x; out.texels[3 * i + 1] = d->texels[i].y; out.texels[3 * i + 2] = d->texels[i].z; }
+    out.lights.resize(d->light_count ? d->light_count : 1);
+    for (uint64_t i = 0; i < d->light_count; i++) {
+        const RtLight& s = d->lights[i]; DevLight& l = out.lights[i];
+        l.w[0].u[0] = s.kind; l.w[0].f[1] = s.intensity; l.w[0].f[2] = s.angle_deg; l.w[0].f[3] = 0.0f;
+        l.w[1].f[0] = s.origin.x; l.w[1].f[1] = s.origin.y; l.w[1].f[2] = s.origin.z; l.w[1].f[3] = 0.0f;
+        l.w[2].f[0] = s.direction.x; l.w[2].f[1] = s.direction.y; l.w[2].f[2] = s.direction.z; l.w[2].f[3] = 0.0f;
+        l.w[3].f[0] = s.color.x; l.w[3].f[1] = s.color.y; l.w[3].f[2] = s.color.z; l.w[3].f[3] = 0.0f;
+    }
+    if (out.meshes.empty()) out.meshes.emplace_back();
+    if (out.tri_hot.empty()) { out.tri_hot.emplace_back(); out.tri_cold.emplace_back(); out.tri_rank.push_back(0); }
+
+    // traversal stack: one deferred sibling per inner level of the TLAS, one
+    // TLAS-leaf continuation, one per inner level of the deepest BLAS, + margin
+    v.stack_entries = out.info.tlas_depth + 1 + out.info.blas_depth + 2;
+    return RT_OK;
+}
+
+int host_create_render_chunks(uint32_t width, uint32_t height, uint32_t count_x, uint32_t count_y, RtRenderChunk* out, uint32_t capacity) {
+    if (count_x == 0 || count_y == 0 || !out) return RT_E_INVALID;
+    if ((uint64_t)count_x * count_y > capacity) return RT_E_INVALID;
+    // viewport.rs:35-43: equal segments, the remainder goes to the last one
+    const uint32_t sw = width / count_x, rw = width % count_x, sh = height / count_y, rh = height % count_y;
+    uint32_t n = 0;
+    for (uint32_t j = 0; j < count_y; j++)
+        for (uint32_t i = 0; i < count_x; i++)
+            out[n++] = RtRenderChunk{i * sw, j * sh, i == count_x - 1 ? sw + rw : sw, j == count_y - 1 ? sh + rh : sh};
+    return (int)n;
+}
+
+void host_v3_to_rgba(const float* rgb, uint64_t n_pixels, uint8_t* o) {
+    // `(255.0 * c) as u8`: truncating, saturating, NaN -> 0 (src/rgba.rs:6-12)
+    auto cvt = [](float c) -> uint8_t { const float s = 255.0f * c; if (!(s > 0.0f)) return 0; if (s >= 255.0f) return 255; return (uint8_t)s; };
+    for (uint64_t i = 0; i < n_pixels; i++) { o[4 * i] = cvt(rgb[3 * i]); o[4 * i + 1] = cvt(rgb[3 * i + 1]); o[4 * i + 2] = cvt(rgb[3 * i + 2]); o[4 * i + 3] = 255; }
+}
