@@ -309,6 +309,14 @@ int rt_scene_info(const RtScene* scene, RtSceneInfo* out);
 int64_t rt_scene_bvh_order(const RtScene* scene, int64_t mesh_index,
                            uint32_t* out, uint64_t capacity);
 
+/* Measurement hook (no reference counterpart; the reference only logs wall time,
+ * src/job_running.rs:44): while enabled, every launch of the render kernel on
+ * this scene is bracketed by HIP events on the stream it is launched on.
+ * rt_scene_profile_read waits for those events, returns the summed kernel time
+ * and the number of launches since the last read, and clears the list. */
+int rt_scene_profile_enable(RtScene* scene, int enable);
+int rt_scene_profile_read(RtScene* scene, double* kernel_ms_total, uint64_t* launches);
+
 #ifdef __cplusplus
 }
 #endif

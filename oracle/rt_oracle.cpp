@@ -1109,12 +1109,13 @@ int orc_accumulate_chunk(const OrcScene* s, const RtSettings* st, const RtRender
 }
 
 int orc_render_chunks_mt(const OrcScene* s, const RtSettings* st, uint32_t count_x, uint32_t count_y,
-                         uint32_t chunk_first, uint32_t chunk_count, uint32_t threads, int rng_mode, uint64_t seed,
+                         uint32_t chunk_first, uint32_t chunk_stride, uint32_t chunk_count, uint32_t threads, int rng_mode, uint64_t seed,
                          int stats, OrcCounters* counters, double* elapsed_ms) {
     if (!s || !validate_settings(st, nullptr) || count_x == 0 || count_y == 0 || threads == 0)
         return fail(RT_E_INVALID, "orc_render_chunks_mt: bad arguments");
     std::vector<RtRenderChunk> chunks = create_render_chunks(st->width, st->height, count_x, count_y);
-    if ((uint64_t)chunk_first + chunk_count > chunks.size()) return fail(RT_E_INVALID, "chunk range out of bounds");
+    if (chunk_stride == 0 || chunk_count == 0 || (uint64_t)chunk_first + (uint64_t)(chunk_count - 1) * chunk_stride >= chunks.size())
+        return fail(RT_E_INVALID, "chunk sample out of bounds");
     RankTables rk; if (stats) rk = make_ranks(*s);
     std::atomic<uint32_t> next{0}; std::atomic<int> err{0};
     std::vector<Counters> per_thread(threads);
@@ -1124,7 +1125,7 @@ int orc_render_chunks_mt(const OrcScene* s, const RtSettings* st, uint32_t count
         for (;;) {
             uint32_t i = next.fetch_add(1);
             if (i >= chunk_count) break;
-            try { render_chunk_impl(*s, *st, chunks[chunk_first + i], rng_mode, seed, 0, stats ? &rk : nullptr, nullptr, nullptr, 0, per_thread[t]); }
+            try { render_chunk_impl(*s, *st, chunks[chunk_first + (size_t)i * chunk_stride], rng_mode, seed, 0, stats ? &rk : nullptr, nullptr, nullptr, 0, per_thread[t]); }
             catch (StackOverflow&) { err = RT_E_DEPTH; break; }
         }
     });

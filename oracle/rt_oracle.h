@@ -80,11 +80,11 @@ int orc_render_image_mt(const OrcScene* s, const RtSettings* settings,
                         float* rgb_out, uint8_t* rgba_out,
                         OrcCounters* counters, double* elapsed_ms);
 
-/* Same threading model restricted to chunks [chunk_first, chunk_first+chunk_count)
- * of the list: the bounded sample bench.py times. */
+/* Same threading model restricted to the chunks chunk_first + k*chunk_stride
+ * (k < chunk_count) of the list: the bounded sample bench.py times. */
 int orc_render_chunks_mt(const OrcScene* s, const RtSettings* settings,
                          uint32_t count_x, uint32_t count_y,
-                         uint32_t chunk_first, uint32_t chunk_count, uint32_t threads,
+                         uint32_t chunk_first, uint32_t chunk_stride, uint32_t chunk_count, uint32_t threads,
                          int rng_mode, uint64_t seed, int stats,
                          OrcCounters* counters, double* elapsed_ms);
 

@@ -165,6 +165,8 @@ HIP_PROTOTYPES = {
     "rt_v3_to_rgba": (None, [C.c_void_p, C.c_uint64, C.c_void_p]),
     "rt_scene_info": (C.c_int, [C.c_void_p, _P(RtSceneInfo)]),
     "rt_scene_bvh_order": (C.c_int64, [C.c_void_p, C.c_int64, C.c_void_p, C.c_uint64]),
+    "rt_scene_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "rt_scene_profile_read": (C.c_int, [C.c_void_p, _P(C.c_double), _P(C.c_uint64)]),
 }
 
 SAMPLES_PROTOTYPES = {

@@ -29,6 +29,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/rt_hip.h"
@@ -769,6 +770,8 @@ struct RtScene {
     DeviceBuffer partial, accum, out_rgb, out_rgba, ctrl, prim;
     int grid_blocks = 0;
     size_t lds_bytes = 0;
+    bool profiling = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> profile_events;
 };
 
 namespace {
@@ -826,8 +829,11 @@ int enqueue_accumulate(RtScene* scene, const RtSettings* st, const RtRenderChunk
         const uint64_t items = (uint64_t)P.pix_slots * bn;
         uint64_t blocks = (items + RT_BLOCK - 1) / RT_BLOCK;
         if (blocks > (uint64_t)scene->grid_blocks) blocks = scene->grid_blocks;
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        if (scene->profiling) { HIP_TRY(hipEventCreate(&ev0)); HIP_TRY(hipEventCreate(&ev1)); HIP_TRY(hipEventRecord(ev0, stream)); }
         hipLaunchKernelGGL(render_kernel, dim3((uint32_t)blocks), dim3(RT_BLOCK), scene->lds_bytes, stream, scene->view, P);
         HIP_TRY(hipGetLastError());
+        if (scene->profiling) { HIP_TRY(hipEventRecord(ev1, stream)); scene->profile_events.emplace_back(ev0, ev1); }
         hipLaunchKernelGGL(fold_kernel, dim3((npix + 255) / 256), dim3(256), 0, stream, (const float*)scene->partial.p, bn, npix, acc, acc_pitch,
                            ch->width, acc_x, acc_y, (init_zero && b0 == 0) ? 1 : 0);
         HIP_TRY(hipGetLastError());
@@ -988,6 +994,31 @@ void rt_v3_to_rgba(const float* rgb, uint64_t n_pixels, uint8_t* rgba_out) { hos
 int rt_scene_info(const RtScene* scene, RtSceneInfo* out) {
     if (!scene || !out) return set_error(RT_E_INVALID, "null argument");
     *out = scene->info;
+    return RT_OK;
+}
+
+int rt_scene_profile_enable(RtScene* scene, int enable) {
+    if (!scene) return set_error(RT_E_INVALID, "null scene");
+    std::lock_guard<std::mutex> g(scene->lock);
+    scene->profiling = enable != 0;
+    return RT_OK;
+}
+
+int rt_scene_profile_read(RtScene* scene, double* kernel_ms_total, uint64_t* launches) {
+    if (!scene) return set_error(RT_E_INVALID, "null scene");
+    std::lock_guard<std::mutex> g(scene->lock);
+    HIP_TRY(hipSetDevice(scene->device));
+    double total = 0.0;
+    for (auto& ev : scene->profile_events) {
+        HIP_TRY(hipEventSynchronize(ev.second));
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, ev.first, ev.second));
+        total += ms;
+        (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second);
+    }
+    if (kernel_ms_total) *kernel_ms_total = total;
+    if (launches) *launches = scene->profile_events.size();
+    scene->profile_events.clear();
     return RT_OK;
 }
 

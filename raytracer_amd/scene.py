@@ -295,6 +295,15 @@ class Scene:
         self._check(self._lib.rt_accumulate_chunk_device(self._h, C.byref(settings.c), C.byref(chunk), seed,
                                                          sample_first, sample_count, accum_ptr, counters_ptr, stream))
 
+    def profile_enable(self, enable=True):
+        self._check(self._lib.rt_scene_profile_enable(self._h, 1 if enable else 0))
+
+    def profile_read(self):
+        """(summed render-kernel milliseconds, launches) since the last read."""
+        ms, n = C.c_double(), C.c_uint64()
+        self._check(self._lib.rt_scene_profile_read(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
     def primary_hits(self, settings, chunk):
         """(t, normal, entity index, triangle index) of the first hit_closest per pixel."""
         h, w = chunk.height, chunk.width

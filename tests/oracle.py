@@ -38,7 +38,8 @@ _PROTOS = {
     "orc_render_image_mt": (C.c_int, [C.c_void_p, _P(RtSettings), C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
                                       C.c_uint64, C.c_void_p, C.c_void_p, _P(OrcCounters), _P(C.c_double)]),
     "orc_render_chunks_mt": (C.c_int, [C.c_void_p, _P(RtSettings), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
-                                       C.c_uint32, C.c_int, C.c_uint64, C.c_int, _P(OrcCounters), _P(C.c_double)]),
+                                       C.c_uint32, C.c_uint32, C.c_int, C.c_uint64, C.c_int, _P(OrcCounters),
+                                       _P(C.c_double)]),
     "orc_primary_hits": (C.c_int, [C.c_void_p, _P(RtSettings), _P(RtRenderChunk), C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p]),
     "orc_scene_bvh_order": (C.c_int64, [C.c_void_p, C.c_int64, C.c_void_p, C.c_uint64]),
@@ -142,12 +143,12 @@ class OracleScene:
                                                   seed, rgb.ctypes.data, rgba.ctypes.data, C.byref(cn), C.byref(ms)))
         return rgb, rgba, cn, ms.value
 
-    def render_chunks_mt(self, settings, count, chunk_first, chunk_count, threads, rng_mode=ORC_RNG_XORSHIFT_CHUNK,
-                         seed=12345, stats=False):
+    def render_chunks_mt(self, settings, count, chunk_first, chunk_stride, chunk_count, threads,
+                         rng_mode=ORC_RNG_XORSHIFT_CHUNK, seed=12345, stats=False):
         cn = OrcCounters()
         ms = C.c_double()
         self._check(self._lib.orc_render_chunks_mt(self._h, C.byref(settings.c), count[0], count[1], chunk_first,
-                                                   chunk_count, threads, rng_mode, seed, 1 if stats else 0,
+                                                   chunk_stride, chunk_count, threads, rng_mode, seed, 1 if stats else 0,
                                                    C.byref(cn), C.byref(ms)))
         return cn, ms.value
 
