@@ -204,7 +204,8 @@ _samples_lib = None
 
 
 def hip_library_path():
-    return os.path.join(_HERE, "librt_hip.so")
+    # RT_HIP_LIB: A/B an alternative build of the same library (experiments only)
+    return os.environ.get("RT_HIP_LIB") or os.path.join(_HERE, "librt_hip.so")
 
 
 def samples_library_path():

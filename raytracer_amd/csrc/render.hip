@@ -26,6 +26,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -43,6 +44,9 @@
 #define RT_SAMPLE_SEGMENT 32u
 #define RT_BLOCK 256
 #define RT_PENDING_MAX 8
+#ifndef RT_WAVES_PER_SIMD
+#define RT_WAVES_PER_SIMD 4     /* register budget of the render kernel: 512 / 4 -> 128 VGPRs */
+#endif
 #define RT_MAX_REFLECTIONS 31u
 
 namespace {
@@ -121,22 +125,28 @@ struct Hit {
     uint32_t erank;    // reference visit rank of the entity (tie breaking)
 };
 
-// implementation.rs:92-118 for one box; `entry` = the updated t_min.  The
-// per-axis early exit of the reference is equivalent to testing once at the end
-// (t_min only grows, t_max only shrinks, NaN never enters either).
+// implementation.rs:92-118.  The reference walks the axes in turn:
+//     inv_d = 1/dir; t0 = (min-o)*inv_d; t1 = (max-o)*inv_d; if inv_d < 0 swap;
+//     t_min = t0 > t_min ? t0 : t_min;  t_max = t1 < t_max ? t1 : t_max;  if t_max < t_min -> miss
+// Same values here, arranged for the VALU:
+//   * the swap is applied to the box planes before the arithmetic (the products are
+//     the same two numbers either way);
+//   * `x > t ? x : t` with t never NaN is exactly fmaxf(x, t) (a NaN x is ignored by
+//     both; +-0 order is irrelevant to every later comparison), and max / min are
+//     associative, so the three axes fold into v_max3 / v_min3;
+//   * the per-axis early exit equals one test at the end (t_min only grows, t_max only
+//     shrinks, NaN never enters either).
+// `entry` = the final t_min (used to order the two children).
 __device__ __forceinline__ bool slab(float lox, float loy, float loz, float hix, float hiy, float hiz,
                                      F3 o, F3 inv, float t_min, float t_max, float& entry) {
-    float t0 = (lox - o.x) * inv.x, t1 = (hix - o.x) * inv.x;
-    if (inv.x < 0.0f) { const float s = t0; t0 = t1; t1 = s; }
-    t_min = t0 > t_min ? t0 : t_min; t_max = t1 < t_max ? t1 : t_max;
-    t0 = (loy - o.y) * inv.y; t1 = (hiy - o.y) * inv.y;
-    if (inv.y < 0.0f) { const float s = t0; t0 = t1; t1 = s; }
-    t_min = t0 > t_min ? t0 : t_min; t_max = t1 < t_max ? t1 : t_max;
-    t0 = (loz - o.z) * inv.z; t1 = (hiz - o.z) * inv.z;
-    if (inv.z < 0.0f) { const float s = t0; t0 = t1; t1 = s; }
-    t_min = t0 > t_min ? t0 : t_min; t_max = t1 < t_max ? t1 : t_max;
-    entry = t_min;
-    return !(t_max < t_min);
+    const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
+    const float ax = ((nx ? hix : lox) - o.x) * inv.x, bx = ((nx ? lox : hix) - o.x) * inv.x;
+    const float ay = ((ny ? hiy : loy) - o.y) * inv.y, by = ((ny ? loy : hiy) - o.y) * inv.y;
+    const float az = ((nz ? hiz : loz) - o.z) * inv.z, bz = ((nz ? loz : hiz) - o.z) * inv.z;
+    const float tn = fmaxf(fmaxf(fmaxf(ax, ay), az), t_min);
+    const float tf = fminf(fminf(fminf(bx, by), bz), t_max);
+    entry = tn;
+    return !(tf < tn);
 }
 
 // Entity::hit's world -> entity ray transform, implementation.rs:288-294
@@ -164,13 +174,18 @@ __device__ __forceinline__ void trace(const DevSceneView& S, const F3 wo, const 
     best.t = t_max; best.ent = RT_NONE; best.tri = RT_NONE; best.erank = 0;
     float best_t = t_max;                 // culling bound; primitives test against [t_min, t_max]
 
-    const F3 winv = f3(1.0f / wd.x, 1.0f / wd.y, 1.0f / wd.z);
-    F3 o = wo, d = wd, inv = winv;
-    uint32_t sp = 0, inst_sp = 0;
-    bool in_blas = false;
+    F3 o = wo, d = wd, inv = f3(1.0f / wd.x, 1.0f / wd.y, 1.0f / wd.z);
+    uint32_t sp = 0, inst_sp = RT_NONE;    // inst_sp != NONE: inside a BLAS entered at that stack height
     const DevNode* nodes = S.nodes;        // current BVH's node base
     uint32_t tri_base = 0;                 // current BLAS
     uint32_t cur_ent = 0, cur_erank = 0;
+
+    // next deferred subtree; leaving a BLAS restores the world-space ray
+    auto pop = [&]() -> uint32_t {
+        if (sp == inst_sp) { inst_sp = RT_NONE; o = wo; d = wd; inv = f3(1.0f / wd.x, 1.0f / wd.y, 1.0f / wd.z); nodes = S.nodes; }
+        if (sp == 0) return RT_NONE;
+        return stack[(--sp) * RT_BLOCK];
+    };
 
     uint32_t cur;
     {
@@ -179,13 +194,9 @@ __device__ __forceinline__ void trace(const DevSceneView& S, const F3 wo, const 
                   ? S.tlas_root_ref : RT_NONE;
     }
     for (;;) {
-        if (cur == RT_NONE) {
-            if (in_blas && sp == inst_sp) { in_blas = false; o = wo; d = wd; inv = winv; nodes = S.nodes; }
-            if (sp == 0) break;
-            cur = stack[(--sp) * RT_BLOCK];
-        }
-        if (!(cur & RT_REF_LEAF_BIT)) {
-            // ---- inner node: one 64-byte record, two boxes ------------------
+        // ---- phase 1: walk inner nodes until this lane holds a leaf (RT_NONE has the
+        // leaf bit set and ends the walk too).  One 64-byte record = two boxes. ------
+        while (cur < RT_REF_LEAF_BIT) {
             const Word4* n = nodes[cur].w;
             const Word4 a = ldw(n), b = ldw(n + 1), c = ldw(n + 2), r = ldw(n + 3);
             float el, er;
@@ -196,14 +207,14 @@ __device__ __forceinline__ void trace(const DevSceneView& S, const F3 wo, const 
                 const uint32_t far_ref = left_first ? r.u[1] : r.u[0];
                 cur = left_first ? r.u[0] : r.u[1];
                 if (sp < stack_cap) stack[(sp++) * RT_BLOCK] = far_ref;
-            } else cur = hl ? r.u[0] : (hr ? r.u[1] : RT_NONE);
-            continue;
+            } else if (hl || hr) cur = hl ? r.u[0] : r.u[1];
+            else cur = pop();
         }
-        // ---- leaf -------------------------------------------------------------
+        if (cur == RT_NONE) break;
+        // ---- phase 2: the leaf ---------------------------------------------------------
         const uint32_t first = cur & RT_REF_FIRST_MASK;
         const uint32_t count = ((cur >> RT_REF_COUNT_SHIFT) & 7u) + 1u;
-        cur = RT_NONE;
-        if (in_blas) {
+        if (inst_sp != RT_NONE) {
             // try_hit_tri, mesh.rs:18-76 (normal precomputed with the same ops)
             for (uint32_t k = 0; k < count; k++) {
                 const uint32_t ti = tri_base + first + k;
@@ -231,64 +242,70 @@ __device__ __forceinline__ void trace(const DevSceneView& S, const F3 wo, const 
                 }
                 if (better) { best.t = t; best.ent = cur_ent; best.tri = ti; best.erank = cur_erank; best_t = t; }
             }
+            cur = pop();
             continue;
         }
-        // TLAS leaf: one entity per visit, the rest goes back on the stack
-        if (count > 1 && sp < stack_cap)
-            stack[(sp++) * RT_BLOCK] = RT_REF_LEAF_BIT | ((count - 2) << RT_REF_COUNT_SHIFT) | (first + 1);
-        const Word4* ew = S.entities[first].w;
-        const Word4 e0 = ldw(ew), e1 = ldw(ew + 1), e2 = ldw(ew + 2);
-        const uint32_t kind = e1.u[0] & 0xff;
-        F3 eo = wo, ed = wd;
-        ray_to_entity(S, e0, e1, eo, ed);
-        if (kind == RT_HITABLE_SPHERE) {
-            // intersect_sphere + Sphere::hit, sphere.rs:4-17, 36-39
-            const float radius = e0.f[3];
-            const float qa = dot(ed, ed);
-            const float qb = dot(eo, ed);
-            const float qc = dot(eo, eo) - radius * radius;
-            const float discriminant = qb * qb - qa * qc;
-            if (discriminant > 0.0f) {
-                const float sq = sqrtf(discriminant);
-                const float t0 = (-qb - sq) / qa, t1 = (-qb + sq) / qa;
-                const bool in0 = t_min < t0 && t0 < t_max, in1 = t_min < t1 && t1 < t_max;
-                if (in0 || in1) {
-                    const float t = (in0 && in1) ? fminf(t0, t1) : (in0 ? t0 : t1);
-                    if (best.ent == RT_NONE || t < best_t || (t == best_t && e2.u[3] < best.erank)) {
-                        best.t = t; best.ent = first; best.tri = RT_NONE; best.erank = e2.u[3]; best_t = t;
-                    }
+        // TLAS leaf: its entities in order; a mesh entity defers the rest of the leaf
+        // and turns the walk into its BLAS.
+        bool entered = false;
+        for (uint32_t k = 0; k < count && !entered; k++) {
+            const uint32_t ei = first + k;
+            const Word4* ew = S.entities[ei].w;
+            const Word4 e0 = ldw(ew), e1 = ldw(ew + 1);
+            const uint32_t kind = e1.u[0] & 0xff;
+            F3 eo = wo, ed = wd;
+            ray_to_entity(S, e0, e1, eo, ed);
+            float t = 0.0f; bool hit = false;
+            if (kind == RT_HITABLE_SPHERE) {
+                // intersect_sphere + Sphere::hit, sphere.rs:4-17, 36-39
+                const float radius = e0.f[3];
+                const float qa = dot(ed, ed);
+                const float qb = dot(eo, ed);
+                const float qc = dot(eo, eo) - radius * radius;
+                const float discriminant = qb * qb - qa * qc;
+                if (discriminant > 0.0f) {
+                    const float sq = sqrtf(discriminant);
+                    const float t0 = (-qb - sq) / qa, t1 = (-qb + sq) / qa;
+                    const bool in0 = t_min < t0 && t0 < t_max, in1 = t_min < t1 && t1 < t_max;
+                    hit = in0 || in1;
+                    t = (in0 && in1) ? fminf(t0, t1) : (in0 ? t0 : t1);
+                }
+            } else if (kind == RT_HITABLE_PLANE) {
+                // intersect_plane + Plane::hit, plane.rs:4-17, 59-70
+                const Word4* pw = S.planes[e1.u[1]].w;
+                const Word4 p0 = ldw(pw), p1 = ldw(pw + 1);
+                const F3 pn = w3(p0);
+                const float denominator = dot(ed, pn);
+                if (!(fabsf(denominator) < 1.0e-6f)) {
+                    t = dot(f3(0.0f, 0.0f, 0.0f) - eo, pn) / denominator;
+                    hit = !(t < t_min || t > t_max);
+                    if (hit && p1.u[3]) { const F3 p = eo + (ed * t); hit = !(length(p) > p0.f[3]); }
+                }
+            } else {
+                // MeshObject::hit -> BLAS (mesh.rs:161-176): enter the instance
+                const Word4* mw = S.meshes[e1.u[1]].w;
+                const Word4 m0 = ldw(mw), m1 = ldw(mw + 1), m2 = ldw(mw + 2);
+                const F3 einv = f3(1.0f / ed.x, 1.0f / ed.y, 1.0f / ed.z);
+                float e;
+                if (slab(m1.f[0], m1.f[1], m1.f[2], m1.f[3], m2.f[0], m2.f[1], eo, einv, t_min, best_t, e)) {
+                    if (k + 1 < count && sp < stack_cap)
+                        stack[(sp++) * RT_BLOCK] = RT_REF_LEAF_BIT | ((count - k - 2) << RT_REF_COUNT_SHIFT) | (ei + 1);
+                    inst_sp = sp;
+                    o = eo; d = ed; inv = einv;
+                    nodes = S.nodes + m0.u[0]; tri_base = m0.u[1];
+                    cur_ent = ei; cur_erank = ldw(ew + 2).u[3];
+                    cur = m0.u[3];
+                    entered = true;
                 }
             }
-        } else if (kind == RT_HITABLE_PLANE) {
-            // intersect_plane + Plane::hit, plane.rs:4-17, 59-70
-            const Word4* pw = S.planes[e1.u[1]].w;
-            const Word4 p0 = ldw(pw), p1 = ldw(pw + 1);
-            const F3 pn = w3(p0);
-            const float denominator = dot(ed, pn);
-            if (!(fabsf(denominator) < 1.0e-6f)) {
-                const float t = dot(f3(0.0f, 0.0f, 0.0f) - eo, pn) / denominator;
-                if (!(t < t_min || t > t_max)) {
-                    bool ok = true;
-                    if (p1.u[3]) { const F3 p = eo + (ed * t); ok = !(length(p) > p0.f[3]); }
-                    if (ok && (best.ent == RT_NONE || t < best_t || (t == best_t && e2.u[3] < best.erank))) {
-                        best.t = t; best.ent = first; best.tri = RT_NONE; best.erank = e2.u[3]; best_t = t;
-                    }
+            if (hit) {
+                const uint32_t erank = ldw(ew + 2).u[3];
+                if (best.ent == RT_NONE || t < best_t || (t == best_t && erank < best.erank)) {
+                    best.t = t; best.ent = ei; best.tri = RT_NONE; best.erank = erank; best_t = t;
                 }
-            }
-        } else {
-            // MeshObject::hit -> BLAS (mesh.rs:161-176): enter the instance
-            const Word4* mw = S.meshes[e1.u[1]].w;
-            const Word4 m0 = ldw(mw), m1 = ldw(mw + 1), m2 = ldw(mw + 2);
-            const F3 einv = f3(1.0f / ed.x, 1.0f / ed.y, 1.0f / ed.z);
-            float e;
-            if (slab(m1.f[0], m1.f[1], m1.f[2], m1.f[3], m2.f[0], m2.f[1], eo, einv, t_min, best_t, e)) {
-                in_blas = true; inst_sp = sp;
-                o = eo; d = ed; inv = einv;
-                nodes = S.nodes + m0.u[0]; tri_base = m0.u[1];
-                cur_ent = first; cur_erank = e2.u[3];
-                cur = m0.u[3];
             }
         }
+        if (!entered) cur = pop();
     }
 }
 
@@ -476,6 +493,7 @@ struct RenderParams {
     uint32_t tiles_x, pix_slots;                    // 8x8 tiling of the chunk; pix_slots = tiles*64
     float* partial;                                 // [seg_count][cw*ch][3] segment sums
     unsigned long long* counters;                   // RtRayCounters on the device (nullable)
+    uint32_t refill_lanes;                          // idle lanes that end a traversal burst
 };
 
 __device__ __forceinline__ void gen_camera_ray(const DevSceneView& S, const RenderParams& P, uint32_t px, uint32_t py, float lx, float ly, F3& o, F3& d) {
@@ -488,21 +506,29 @@ __device__ __forceinline__ void gen_camera_ray(const DevSceneView& S, const Rend
     d = ld3(S.cam_llc) + (ld3(S.cam_horizontal) * u) + (ld3(S.cam_vertical) * v) - ld3(S.cam_origin) - offset;
 }
 
-__global__ void __launch_bounds__(RT_BLOCK)
+// How many lanes of a wave must be waiting for a new ray before the wave leaves
+// the traversal burst to shade / refill them (persistent-thread ray refill).
+#ifndef RT_REFILL_LANES
+#define RT_REFILL_LANES 64
+#endif
+
+__global__ void __launch_bounds__(RT_BLOCK, RT_WAVES_PER_SIMD)
 render_kernel(const DevSceneView S, const RenderParams P) {
     extern __shared__ uint32_t lds_stack[];
     uint32_t* stack = lds_stack + threadIdx.x;
     const uint32_t stack_cap = S.stack_entries;
 
-    const uint64_t total_items = (uint64_t)P.pix_slots * P.seg_count;
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    uint64_t item = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t total_items = P.pix_slots * P.seg_count;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
 
     uint32_t n_primary = 0, n_secondary = 0, n_shadow = 0, n_samples = 0;
 
-    // lane state
-    enum { NEED_ITEM = 0, NEED_SAMPLE = 1, NEED_PATH = 2, PATH_READY = 3, NEED_LIGHT = 4, SHADOW_READY = 5, FINISHED = 6 };
-    int state = NEED_ITEM;
+    // Lane state between two rays.  PATH / SHADOW: a ray of that kind is in flight
+    // (or, with `tracing` false, has just finished and waits for its shading).
+    enum { PATH = 0, SHADOW = 1, NEED_LIGHT = 2, NEED_PATH = 3, NEED_SAMPLE = 4, FINISHED = 5 };
+    int state = NEED_SAMPLE;
+    bool tracing = false, have_item = false;
     uint32_t px = 0, py = 0, s = 0, s_end = 0, out_slot = 0;
     F3 seg_sum = f3(0, 0, 0), sample_col = f3(0, 0, 0);
     Pending pend[RT_PENDING_MAX]; uint32_t npend = 0;
@@ -512,156 +538,334 @@ render_kernel(const DevSceneView S, const RenderParams P) {
     uint32_t light_k = 0;
     F3 lcol = f3(0, 0, 0), ldir = f3(0, 0, 1); float l_t = 0.0f, closest = 0.0f;
 
+    // Traversal state of the ray in flight (resumable: survives leaving the burst).
+    // The search itself is Scene::hit_closest (implementation.rs:372-375) =
+    // EntityBvhRoot::try_hit (:411-416) over Entity::hit (:285-310) over Sphere::hit /
+    // Plane::hit / MeshBvhRoot::try_hit (sphere.rs:36-53, plane.rs:59-90, mesh.rs:92-99).
+    F3 o = f3(0, 0, 0), d = f3(0, 0, 1), inv = f3(0, 0, 0);
+    float t_min = 0.0f, t_max = 0.0f, best_t = 0.0f;
+    Hit best; best.t = 0.0f; best.ent = RT_NONE; best.tri = RT_NONE; best.erank = 0;
+    uint32_t cur = RT_NONE, sp = 0, inst_sp = RT_NONE, tri_base = 0, cur_ent = 0, cur_erank = 0;
+    const DevNode* nodes = S.nodes;
+
     for (;;) {
-        // ---- cheap transitions until this lane has a ray to trace (or is done) --
-        while (state != PATH_READY && state != SHADOW_READY && state != FINISHED) {
-            if (state == NEED_ITEM) {
+        if (!tracing) {
+            // ================= shading of the ray that just finished =====================
+            if (state == SHADOW) {
+                // cast_light_ray_to_lamp, implementation.rs:535-552
+                n_shadow++;
+                state = NEED_LIGHT;
+                if (best.ent == RT_NONE) {
+                    lsum = lsum + (lcol * fmaxf(0.0f, dot(hn, -ldir)));                    // :615-619
+                    light_k++;
+                } else {
+                    // Only a dielectric can let light through (scatter yields a refraction only
+                    // there, materials.rs:45-53,90-112,168-190): look at the material first,
+                    // rebuild the hit record only if needed.
+                    const uint32_t mat_id = ldw(S.entities[best.ent].w + 1).u[3];
+                    const Word4* mw = S.materials[mat_id].w;
+                    const Word4 m0 = ldw(mw);
+                    if (m0.u[0] == RT_MAT_DIELECTRIC) {
+                        const F3 td = -ldir;
+                        HitRec hr; resolve_hit(S, hp, td, best, hr);
+                        float nint; F3 outn;
+                        const float kr = dielectric_kr(td, hr.normal, ldw(mw + 1).f[0], nint, outn);
+                        if (!(kr >= 1.0f)) {
+                            const float refr_intensity = (1.0f - kr) * (1.0f - m0.f[3]);
+                            const F3 albedo = texture_value(S, hr.tex_id, hr);
+                            lcol = lcol * (albedo * refr_intensity);                          // :541-543
+                            closest = best.t + RT_BIAS;
+                            state = SHADOW;                                                   // same ray, further on
+                        }
+                    }
+                    if (state == NEED_LIGHT) light_k++;                                      // opaque: ZERO (:548)
+                }
+            } else if (state == PATH) {
+                // cast_ray_recursive, implementation.rs:566-631
+                if (rnode == 1u) n_primary++; else n_secondary++;
+                if (best.ent == RT_NONE) { sample_col = sample_col + (rw * color_sky(S, rd)); state = NEED_PATH; }
+                else {
+                    HitRec hr; resolve_hit(S, ro, rd, best, hr);
+                    const Word4* mw = S.materials[hr.mat_id].w;
+                    const Word4 m0 = ldw(mw);
+                    // Material::scatter
+                    bool has_refl = false, has_refr = false; F3 refl_d = f3(0, 0, 0), refr_d = f3(0, 0, 0); float refl_i = 0.0f, refr_i = 0.0f;
+                    if (m0.u[0] == RT_MAT_LAMBERTIAN) {                                       // materials.rs:44-53
+                        has_refl = true; refl_i = m0.f[1];
+                        if (refl_i > 0.0f) {      // the direction is only ever used when the ray is cast (:593)
+                            float r0, r1; rng_pair(P.seed, px, py, s, rnode, PURPOSE_PATH, r0, r1);
+                            refl_d = random_normal_reflection_angle(hr.normal, r0, r1);
+                        }
+                    } else if (m0.u[0] == RT_MAT_SPECULAR) {                                  // materials.rs:89-112
+                        const F3 reflected = reflect(rd, hr.normal);
+                        F3 scattered = reflected;
+                        if (m0.f[2] != 0.0f) {
+                            float r0, r1; rng_pair(P.seed, px, py, s, rnode, PURPOSE_PATH, r0, r1);
+                            scattered = reflected + (unit(random_normal_reflection_angle(hr.normal, r0, r1)) * m0.f[2]);
+                        }
+                        if (dot(scattered, hr.normal) > 0.0f) { has_refl = true; refl_d = scattered; refl_i = m0.f[1]; }
+                    } else {                                                                  // materials.rs:167-204
+                        float ni_over_nt; F3 outward_normal;
+                        const float kr = dielectric_kr(rd, hr.normal, ldw(mw + 1).f[0], ni_over_nt, outward_normal);
+                        if (!(kr >= 1.0f)) {
+                            has_refr = true;
+                            refr_d = unit(refract(rd, outward_normal, ni_over_nt));
+                            refr_i = (1.0f - kr) * (1.0f - m0.f[3]);
+                        }
+                        has_refl = true; refl_d = unit(reflect(rd, hr.normal)); refl_i = kr * m0.f[1];
+                    }
+                    // depth budget split, :577-589
+                    const uint32_t rl = rlimit - 1u;
+                    uint32_t reflect_limit = 0u, refract_limit = 0u;
+                    if (has_refl && has_refr) { reflect_limit = rl / 2u; refract_limit = rl - reflect_limit; }
+                    else if (has_refl) reflect_limit = rl;
+                    else if (has_refr) refract_limit = rl;
+                    const bool cast_refl = has_refl && refl_i > 0.0f, cast_refr = has_refr && refr_i > 0.0f;   // :593, :601
+                    const float reflection_intensity = cast_refl ? refl_i : 0.0f, refraction_intensity = cast_refr ? refr_i : 0.0f;
+                    const F3 albedo = texture_value(S, hr.tex_id, hr);                        // :626
+                    wa = rw * albedo;
+                    li = fmaxf(0.0f, 1.0f - (reflection_intensity + refraction_intensity));   // :625
+                    // children: colour is linear in them, so they carry weight w*albedo*intensity.
+                    // Refraction is deferred first so that reflection is evaluated first (:592-605).
+                    if (cast_refr) {
+                        const F3 cw_ = wa * refraction_intensity;
+                        if (refract_limit == 0u) sample_col = sample_col + (cw_ * color_sky(S, refr_d));   // :562-564
+                        else if (npend < RT_PENDING_MAX) { Pending& q = pend[npend++]; q.o = hr.p; q.d = refr_d; q.w = cw_; q.limit = refract_limit; q.node = rnode * 2u + 1u; }
+                    }
+                    if (cast_refl) {
+                        const F3 cw_ = wa * reflection_intensity;
+                        if (reflect_limit == 0u) sample_col = sample_col + (cw_ * color_sky(S, refl_d));
+                        else if (npend < RT_PENDING_MAX) { Pending& q = pend[npend++]; q.o = hr.p; q.d = refl_d; q.w = cw_; q.limit = reflect_limit; q.node = rnode * 2u; }
+                    }
+                    // lights, :608-621
+                    hp = hr.p + (hr.normal * RT_BIAS); hn = hr.normal;
+                    lsum = f3(0.0f, 0.0f, 0.0f); light_k = 0u;
+                    state = NEED_LIGHT;
+                }
+            }
+            // ================= next ray of this lane =======================================
+            // stage A: next light of the current hit (implementation.rs:612-621)
+            if (state == NEED_LIGHT) {
+                while (light_k < S.light_count) {
+                    LightRec lr;
+                    if (light_record(S, light_k, hp, lr)) {
+                        lcol = lr.color * lr.intensity; ldir = lr.direction; l_t = lr.t; closest = RT_BIAS;   // :527-532
+                        state = SHADOW;
+                        break;
+                    }
+                    light_k++;
+                }
+                if (state == NEED_LIGHT) {
+                    // (color_from_lights * lights_intensity) * albedo, weighted (:628-630)
+                    sample_col = sample_col + (wa * (lsum * li));
+                    state = NEED_PATH;
+                }
+            }
+            // stage B: next ray of the current sample's recursion tree
+            if (state == NEED_PATH) {
+                if (npend != 0) {
+                    const Pending& q = pend[--npend];
+                    ro = q.o; rd = q.d; rw = q.w; rlimit = q.limit; rnode = q.node;
+                    state = PATH;
+                } else {
+                    // cast_ray's clamp (:635, types.rs:46-50) then col = col + sample (:656)
+                    const F3 c = f3(fmaxf(fminf(sample_col.x, 1.0f), -1.0f), fmaxf(fminf(sample_col.y, 1.0f), -1.0f), fmaxf(fminf(sample_col.z, 1.0f), -1.0f));
+                    seg_sum = seg_sum + c;
+                    s++; state = NEED_SAMPLE;
+                }
+            }
+            // stage C: next sample / next work item
+            while (state == NEED_SAMPLE) {
+                if (have_item && s < s_end) {
+                    float lx = 0.0f, ly = 0.0f;
+                    if (P.spp > 1) {                                                  // :648-653
+                        float r0, r1; rng_pair(P.seed, px, py, s, 0u, PURPOSE_LENS, r0, r1);
+                        lx = r0 * 2.0f - 1.0f; ly = r1 * 2.0f - 1.0f;
+                    }
+                    gen_camera_ray(S, P, px, py, lx, ly, ro, rd);
+                    rw = f3(1.0f, 1.0f, 1.0f); rlimit = P.max_reflections; rnode = 1u;
+                    sample_col = f3(0.0f, 0.0f, 0.0f); npend = 0; n_samples++;
+                    if (rlimit == 0) {                                                // :562-564: sky, no ray cast
+                        const F3 sky = color_sky(S, rd);
+                        seg_sum = seg_sum + f3(fmaxf(fminf(sky.x, 1.0f), -1.0f), fmaxf(fminf(sky.y, 1.0f), -1.0f), fmaxf(fminf(sky.z, 1.0f), -1.0f));
+                        s++;
+                    } else state = PATH;
+                    continue;
+                }
+                if (have_item) {
+                    float* out = P.partial + (uint64_t)out_slot * 3;
+                    out[0] = seg_sum.x; out[1] = seg_sum.y; out[2] = seg_sum.z;
+                    have_item = false;
+                }
                 if (item >= total_items) { state = FINISHED; break; }
-                const uint32_t seg_local = (uint32_t)(item / P.pix_slots), q = (uint32_t)(item % P.pix_slots);
+                const uint32_t seg_local = item / P.pix_slots, q = item % P.pix_slots;
                 item += stride;
                 const uint32_t tile = q >> 6, within = q & 63u;
                 const uint32_t x = (tile % P.tiles_x) * 8u + (within & 7u), y = (tile / P.tiles_x) * 8u + (within >> 3);
                 if (x >= P.cw || y >= P.ch) continue;
                 const uint32_t seg = P.seg_first + seg_local;
-                const uint32_t a = seg * RT_SAMPLE_SEGMENT, b = a + RT_SAMPLE_SEGMENT;
+                const uint32_t sa = seg * RT_SAMPLE_SEGMENT, sb = sa + RT_SAMPLE_SEGMENT;
                 const uint32_t r_end = P.sample_first + P.sample_count;
-                s = a > P.sample_first ? a : P.sample_first;
-                s_end = b < r_end ? b : r_end;
+                s = sa > P.sample_first ? sa : P.sample_first;
+                s_end = sb < r_end ? sb : r_end;
                 px = P.left + x; py = P.top + y;
                 out_slot = seg_local * (P.cw * P.ch) + y * P.cw + x;
                 seg_sum = f3(0.0f, 0.0f, 0.0f);
-                state = NEED_SAMPLE;
-            } else if (state == NEED_SAMPLE) {
-                if (s >= s_end) {
-                    float* o = P.partial + (uint64_t)out_slot * 3;
-                    o[0] = seg_sum.x; o[1] = seg_sum.y; o[2] = seg_sum.z;
-                    state = NEED_ITEM; continue;
-                }
-                float lx = 0.0f, ly = 0.0f;
-                if (P.spp > 1) {                                                  // :648-653
-                    float r0, r1; rng_pair(P.seed, px, py, s, 0u, PURPOSE_LENS, r0, r1);
-                    lx = r0 * 2.0f - 1.0f; ly = r1 * 2.0f - 1.0f;
-                }
-                gen_camera_ray(S, P, px, py, lx, ly, ro, rd);
-                rw = f3(1.0f, 1.0f, 1.0f); rlimit = P.max_reflections; rnode = 1u;
-                sample_col = f3(0.0f, 0.0f, 0.0f); npend = 0; n_samples++;
-                if (rlimit == 0) { sample_col = color_sky(S, rd); state = NEED_PATH; }    // :562-564
-                else state = PATH_READY;
-            } else if (state == NEED_PATH) {
-                if (npend == 0) {
-                    // cast_ray's clamp (:635, types.rs:46-50) then col = col + sample (:656)
-                    const F3 c = f3(fmaxf(fminf(sample_col.x, 1.0f), -1.0f), fmaxf(fminf(sample_col.y, 1.0f), -1.0f), fmaxf(fminf(sample_col.z, 1.0f), -1.0f));
-                    seg_sum = seg_sum + c;
-                    s++; state = NEED_SAMPLE; continue;
-                }
-                const Pending& q = pend[--npend];
-                ro = q.o; rd = q.d; rw = q.w; rlimit = q.limit; rnode = q.node;
-                state = PATH_READY;
-            } else {   // NEED_LIGHT: implementation.rs:612-621, one light per shadow ray
-                if (light_k >= S.light_count) {
-                    // (color_from_lights * lights_intensity) * albedo, weighted (:628-630)
-                    sample_col = sample_col + (wa * (lsum * li));
-                    state = NEED_PATH; continue;
-                }
-                LightRec lr;
-                if (!light_record(S, light_k, hp, lr)) { light_k++; continue; }
-                lcol = lr.color * lr.intensity; ldir = lr.direction; l_t = lr.t; closest = RT_BIAS;   // :527-532
-                state = SHADOW_READY;
+                have_item = true;
+            }
+            // ================= start the traversal of the new ray ==========================
+            if (state != FINISHED) {
+                const bool shadow = state == SHADOW;
+                o = shadow ? hp : ro;
+                d = shadow ? -ldir : rd;
+                inv = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                t_min = shadow ? closest : RT_BIAS; t_max = shadow ? l_t : RT_F32_MAX;
+                best.t = t_max; best.ent = RT_NONE; best.tri = RT_NONE; best.erank = 0; best_t = t_max;
+                sp = 0; inst_sp = RT_NONE; nodes = S.nodes;
+                float e;
+                cur = slab(S.tlas_min[0], S.tlas_min[1], S.tlas_min[2], S.tlas_max[0], S.tlas_max[1], S.tlas_max[2], o, inv, t_min, best_t, e)
+                          ? S.tlas_root_ref : RT_NONE;
+                tracing = true;
             }
         }
-        if (state == FINISHED) break;        // this lane is done; the wave runs on until all are
+        if (__ballot(tracing) == 0ull) break;      // every lane of the wave is FINISHED
 
-        // ---- the one traversal every ray kind shares ------------------------------
-        const bool shadow = state == SHADOW_READY;
-        const F3 to = shadow ? hp : ro;
-        const F3 td = shadow ? -ldir : rd;
-        Hit h;
-        trace(S, to, td, shadow ? closest : RT_BIAS, shadow ? l_t : RT_F32_MAX, stack, stack_cap, h);
-
-        if (shadow) {
-            // cast_light_ray_to_lamp, implementation.rs:535-552
-            n_shadow++;
-            if (h.ent == RT_NONE) {
-                lsum = lsum + (lcol * fmaxf(0.0f, dot(hn, -ldir)));                        // :615-619
-                light_k++; state = NEED_LIGHT; continue;
+        // ================= traversal burst ===================================================
+        // next deferred subtree; leaving a BLAS restores the world-space ray
+        auto pop = [&]() -> uint32_t {
+            if (sp == inst_sp) {
+                inst_sp = RT_NONE; nodes = S.nodes;
+                const bool shadow = state == SHADOW;
+                o = shadow ? hp : ro; d = shadow ? -ldir : rd;
+                inv = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
             }
-            HitRec hr; resolve_hit(S, to, td, h, hr);
-            const Word4* mw = S.materials[hr.mat_id].w;
-            const Word4 m0 = ldw(mw);
-            bool transparent = false; float refr_intensity = 0.0f;
-            if (m0.u[0] == RT_MAT_DIELECTRIC) {
-                float nint; F3 outn;
-                const float kr = dielectric_kr(td, hr.normal, ldw(mw + 1).f[0], nint, outn);
-                if (!(kr >= 1.0f)) { transparent = true; refr_intensity = (1.0f - kr) * (1.0f - m0.f[3]); }
+            if (sp == 0) return RT_NONE;
+            return stack[(--sp) * RT_BLOCK];
+        };
+        for (;;) {
+            if (tracing) {
+                // ---- phase 1: walk inner nodes until this lane holds a leaf (RT_NONE has
+                // the leaf bit set and ends the walk too).  One 64-byte record = two boxes.
+                while (cur < RT_REF_LEAF_BIT) {
+                    const Word4* n = nodes[cur].w;
+                    const Word4 na = ldw(n), nb = ldw(n + 1), nc = ldw(n + 2), nr = ldw(n + 3);
+                    float el, er;
+                    const bool hl = slab(na.f[0], na.f[1], na.f[2], na.f[3], nb.f[0], nb.f[1], o, inv, t_min, best_t, el);
+                    const bool hr = slab(nb.f[2], nb.f[3], nc.f[0], nc.f[1], nc.f[2], nc.f[3], o, inv, t_min, best_t, er);
+                    if (hl && hr) {
+                        const bool left_first = el <= er;
+                        const uint32_t far_ref = left_first ? nr.u[1] : nr.u[0];
+                        cur = left_first ? nr.u[0] : nr.u[1];
+                        if (sp < stack_cap) stack[(sp++) * RT_BLOCK] = far_ref;
+                    } else if (hl || hr) cur = hl ? nr.u[0] : nr.u[1];
+                    else cur = pop();
+                }
+                // ---- phase 2: the leaf ------------------------------------------------------
+                if (cur != RT_NONE) {
+                    const uint32_t first = cur & RT_REF_FIRST_MASK;
+                    const uint32_t count = ((cur >> RT_REF_COUNT_SHIFT) & 7u) + 1u;
+                    if (inst_sp != RT_NONE) {
+                        // try_hit_tri, mesh.rs:18-76 (normal precomputed with the same ops)
+                        for (uint32_t k = 0; k < count; k++) {
+                            const uint32_t ti = tri_base + first + k;
+                            const Word4* tw = S.tri_hot[ti].w;
+                            const Word4 ta = ldw(tw), tb = ldw(tw + 1), tc = ldw(tw + 2);
+                            const F3 A = w3(ta), B = w3(tb), C = w3(tc), normal = f3(ta.f[3], tb.f[3], tc.f[3]);
+                            const float denominator = dot(d, normal);                       // plane.rs:7-10
+                            if (fabsf(denominator) < 1.0e-6f) continue;
+                            const float t = dot(A - o, normal) / denominator;               // plane.rs:12-13
+                            if (t < t_min || t > t_max) continue;                           // mesh.rs:28
+                            if (t > best_t) continue;                                       // cannot win
+                            const F3 p = o + (d * t);
+                            const F3 n_abp = cross(B - A, p - A);
+                            if (dot(normal, n_abp) < 0.0f) continue;
+                            const F3 n_bcp = cross(C - B, p - B);
+                            if (dot(normal, n_bcp) < 0.0f) continue;
+                            const F3 n_cap = cross(A - C, p - C);
+                            if (dot(normal, n_cap) < 0.0f) continue;
+                            bool better = best.ent == RT_NONE || t < best_t;
+                            if (!better && t == best_t) {
+                                // exact tie: the reference keeps the candidate it visits first
+                                // (implementation.rs:415, mesh.rs:96-98); ranks are only fetched here
+                                better = cur_erank < best.erank ||
+                                         (cur_erank == best.erank && best.tri != RT_NONE && S.tri_rank[ti] < S.tri_rank[best.tri]);
+                            }
+                            if (better) { best.t = t; best.ent = cur_ent; best.tri = ti; best.erank = cur_erank; best_t = t; }
+                        }
+                        cur = pop();
+                    } else {
+                        // TLAS leaf: its entities in order; a mesh entity defers the rest of the
+                        // leaf and turns the walk into its BLAS.
+                        const bool shadow = state == SHADOW;
+                        const F3 wo = shadow ? hp : ro, wd = shadow ? -ldir : rd;
+                        bool entered = false;
+                        for (uint32_t k = 0; k < count && !entered; k++) {
+                            const uint32_t ei = first + k;
+                            const Word4* ew = S.entities[ei].w;
+                            const Word4 e0 = ldw(ew), e1 = ldw(ew + 1);
+                            const uint32_t kind = e1.u[0] & 0xff;
+                            F3 eo = wo, ed = wd;
+                            ray_to_entity(S, e0, e1, eo, ed);
+                            float t = 0.0f; bool hit = false;
+                            if (kind == RT_HITABLE_SPHERE) {
+                                // intersect_sphere + Sphere::hit, sphere.rs:4-17, 36-39
+                                const float radius = e0.f[3];
+                                const float qa = dot(ed, ed);
+                                const float qb = dot(eo, ed);
+                                const float qc = dot(eo, eo) - radius * radius;
+                                const float discriminant = qb * qb - qa * qc;
+                                if (discriminant > 0.0f) {
+                                    const float sq = sqrtf(discriminant);
+                                    const float t0 = (-qb - sq) / qa, t1 = (-qb + sq) / qa;
+                                    const bool in0 = t_min < t0 && t0 < t_max, in1 = t_min < t1 && t1 < t_max;
+                                    hit = in0 || in1;
+                                    t = (in0 && in1) ? fminf(t0, t1) : (in0 ? t0 : t1);
+                                }
+                            } else if (kind == RT_HITABLE_PLANE) {
+                                // intersect_plane + Plane::hit, plane.rs:4-17, 59-70
+                                const Word4* pw = S.planes[e1.u[1]].w;
+                                const Word4 p0 = ldw(pw), p1 = ldw(pw + 1);
+                                const F3 pn = w3(p0);
+                                const float denominator = dot(ed, pn);
+                                if (!(fabsf(denominator) < 1.0e-6f)) {
+                                    t = dot(f3(0.0f, 0.0f, 0.0f) - eo, pn) / denominator;
+                                    hit = !(t < t_min || t > t_max);
+                                    if (hit && p1.u[3]) { const F3 p = eo + (ed * t); hit = !(length(p) > p0.f[3]); }
+                                }
+                            } else {
+                                // MeshObject::hit -> BLAS (mesh.rs:161-176): enter the instance
+                                const Word4* mw = S.meshes[e1.u[1]].w;
+                                const Word4 m0 = ldw(mw), m1 = ldw(mw + 1), m2 = ldw(mw + 2);
+                                const F3 einv = f3(1.0f / ed.x, 1.0f / ed.y, 1.0f / ed.z);
+                                float e;
+                                if (slab(m1.f[0], m1.f[1], m1.f[2], m1.f[3], m2.f[0], m2.f[1], eo, einv, t_min, best_t, e)) {
+                                    if (k + 1 < count && sp < stack_cap)
+                                        stack[(sp++) * RT_BLOCK] = RT_REF_LEAF_BIT | ((count - k - 2) << RT_REF_COUNT_SHIFT) | (ei + 1);
+                                    inst_sp = sp;
+                                    o = eo; d = ed; inv = einv;
+                                    nodes = S.nodes + m0.u[0]; tri_base = m0.u[1];
+                                    cur_ent = ei; cur_erank = ldw(ew + 2).u[3];
+                                    cur = m0.u[3];
+                                    entered = true;
+                                }
+                            }
+                            if (hit) {
+                                const uint32_t erank = ldw(ew + 2).u[3];
+                                if (best.ent == RT_NONE || t < best_t || (t == best_t && erank < best.erank)) {
+                                    best.t = t; best.ent = ei; best.tri = RT_NONE; best.erank = erank; best_t = t;
+                                }
+                            }
+                        }
+                        if (!entered) cur = pop();
+                    }
+                }
+                if (cur == RT_NONE) tracing = false;      // closest hit (or miss) is in `best`
             }
-            if (transparent) {
-                const F3 albedo = texture_value(S, hr.tex_id, hr);
-                lcol = lcol * (albedo * refr_intensity);                                  // :541-543
-                closest = h.t + RT_BIAS;
-                state = SHADOW_READY;                                                     // same ray, further on
-            } else { light_k++; state = NEED_LIGHT; }                                     // opaque: ZERO (:548)
-            continue;
+            // leave the burst when enough lanes can take a new ray, or nobody is tracing
+            const unsigned long long busy = __ballot(tracing);
+            const unsigned long long refill = __ballot(!tracing && state != FINISHED);
+            if (busy == 0ull || (uint32_t)__popcll(refill) >= P.refill_lanes) break;
         }
-
-        // ---- path ray: cast_ray_recursive, implementation.rs:566-631 ----------------
-        if (rnode == 1u) n_primary++; else n_secondary++;
-        if (h.ent == RT_NONE) { sample_col = sample_col + (rw * color_sky(S, rd)); state = NEED_PATH; continue; }
-        HitRec hr; resolve_hit(S, ro, rd, h, hr);
-        const Word4* mw = S.materials[hr.mat_id].w;
-        const Word4 m0 = ldw(mw);
-        // Material::scatter
-        bool has_refl = false, has_refr = false; F3 refl_d = f3(0, 0, 0), refr_d = f3(0, 0, 0); float refl_i = 0.0f, refr_i = 0.0f;
-        if (m0.u[0] == RT_MAT_LAMBERTIAN) {                                               // materials.rs:44-53
-            has_refl = true; refl_i = m0.f[1];
-            if (refl_i > 0.0f) {          // the direction is only ever used when the ray is cast (:593)
-                float r0, r1; rng_pair(P.seed, px, py, s, rnode, PURPOSE_PATH, r0, r1);
-                refl_d = random_normal_reflection_angle(hr.normal, r0, r1);
-            }
-        } else if (m0.u[0] == RT_MAT_SPECULAR) {                                          // materials.rs:89-112
-            const F3 reflected = reflect(rd, hr.normal);
-            F3 scattered = reflected;
-            if (m0.f[2] != 0.0f) {
-                float r0, r1; rng_pair(P.seed, px, py, s, rnode, PURPOSE_PATH, r0, r1);
-                scattered = reflected + (unit(random_normal_reflection_angle(hr.normal, r0, r1)) * m0.f[2]);
-            }
-            if (dot(scattered, hr.normal) > 0.0f) { has_refl = true; refl_d = scattered; refl_i = m0.f[1]; }
-        } else {                                                                          // materials.rs:167-204
-            float ni_over_nt; F3 outward_normal;
-            const float kr = dielectric_kr(rd, hr.normal, ldw(mw + 1).f[0], ni_over_nt, outward_normal);
-            if (!(kr >= 1.0f)) {
-                has_refr = true;
-                refr_d = unit(refract(rd, outward_normal, ni_over_nt));
-                refr_i = (1.0f - kr) * (1.0f - m0.f[3]);
-            }
-            has_refl = true; refl_d = unit(reflect(rd, hr.normal)); refl_i = kr * m0.f[1];
-        }
-        // depth budget split, :577-589
-        const uint32_t rl = rlimit - 1u;
-        uint32_t reflect_limit = 0u, refract_limit = 0u;
-        if (has_refl && has_refr) { reflect_limit = rl / 2u; refract_limit = rl - reflect_limit; }
-        else if (has_refl) reflect_limit = rl;
-        else if (has_refr) refract_limit = rl;
-        const bool cast_refl = has_refl && refl_i > 0.0f, cast_refr = has_refr && refr_i > 0.0f;   // :593, :601
-        const float reflection_intensity = cast_refl ? refl_i : 0.0f, refraction_intensity = cast_refr ? refr_i : 0.0f;
-        const F3 albedo = texture_value(S, hr.tex_id, hr);                                // :626
-        wa = rw * albedo;
-        li = fmaxf(0.0f, 1.0f - (reflection_intensity + refraction_intensity));           // :625
-        // children: colour is linear in them, so they carry weight w*albedo*intensity.
-        // Refraction is deferred first so that reflection is evaluated first (:592-605).
-        if (cast_refr) {
-            const F3 cw_ = wa * refraction_intensity;
-            if (refract_limit == 0u) sample_col = sample_col + (cw_ * color_sky(S, refr_d));       // :562-564
-            else if (npend < RT_PENDING_MAX) { Pending& q = pend[npend++]; q.o = hr.p; q.d = refr_d; q.w = cw_; q.limit = refract_limit; q.node = rnode * 2u + 1u; }
-        }
-        if (cast_refl) {
-            const F3 cw_ = wa * reflection_intensity;
-            if (reflect_limit == 0u) sample_col = sample_col + (cw_ * color_sky(S, refl_d));
-            else if (npend < RT_PENDING_MAX) { Pending& q = pend[npend++]; q.o = hr.p; q.d = refl_d; q.w = cw_; q.limit = reflect_limit; q.node = rnode * 2u; }
-        }
-        // lights, :608-621
-        hp = hr.p + (hr.normal * RT_BIAS); hn = hr.normal;
-        lsum = f3(0.0f, 0.0f, 0.0f); light_k = 0u;
-        state = NEED_LIGHT;
     }
 
     // ---- ray counters: wave reduce, one atomic per wave and class ------------------
@@ -823,6 +1027,10 @@ int enqueue_accumulate(RtScene* scene, const RtSettings* st, const RtRenderChunk
     P.pix_slots = P.tiles_x * ((ch->height + 7) / 8) * 64;
     P.partial = (float*)scene->partial.p;
     P.counters = counters_dev;
+    {
+        static const uint32_t refill = []() { const char* e = getenv("RT_REFILL_LANES"); int v = e ? atoi(e) : RT_REFILL_LANES; return (uint32_t)(v < 1 ? 1 : (v > 64 ? 64 : v)); }();
+        P.refill_lanes = refill;
+    }
     for (uint32_t b0 = 0; b0 < nseg; b0 += batch) {
         const uint32_t bn = (nseg - b0 < batch) ? nseg - b0 : batch;
         P.seg_first = seg_lo + b0; P.seg_count = bn;
