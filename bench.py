@@ -66,6 +66,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="weekend-1080p-256spp", choices=sorted(WORKLOADS))
+    ap.add_argument("--mode", default="tiles", choices=["tiles", "spp"], help="N>1: tile partition + gather, or spp split + accumulator sum")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-chunk-stride", type=int, default=0, help="oracle sample: every k-th of 32x32 chunks")
     args = ap.parse_args()
@@ -98,45 +99,34 @@ def main():
     info = scene.info()
 
     # ---- work split ---------------------------------------------------------
-    if n_gpus == 1:
-        my_chunks = [RenderChunk(0, 0, W, H)]
-        all_chunks = my_chunks
-    else:
-        strips = 8 * n_gpus
-        all_chunks = create_render_chunks((W, H), (1, strips))
-        my_chunks = [c for i, c in enumerate(all_chunks) if i % n_gpus == rank]
-
-    frame = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)         # rank-local framebuffer
+    from raytracer_amd.dist import StripCompositor, reduce_accumulators, sample_range_of_rank, strip_chunks
+    from raytracer_amd import resolve_device
     counters = torch.zeros(4, dtype=torch.int64, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
-
-    if distributed:
-        # packed strips for the gather: [max rows per rank, W, 3]
-        rows_of = [sum(c.height for i, c in enumerate(all_chunks) if i % n_gpus == r) for r in range(n_gpus)]
-        max_rows = max(rows_of)
-        packed = torch.zeros((max_rows, W, 3), dtype=torch.float32, device=dev)
-        gathered = [torch.zeros_like(packed) for _ in range(n_gpus)] if rank == 0 else None
+    whole = RenderChunk(0, 0, W, H)
+    if args.mode == "tiles":
+        chunks = [whole] if n_gpus == 1 else strip_chunks(W, H, n_gpus)
+        comp = StripCompositor(W, H, chunks, rank, n_gpus, dev)
+        parallelism = "single GPU" if n_gpus == 1 else f"{len(chunks)} strips round-robin over {n_gpus} GPUs + RCCL gather to rank 0"
+    else:
+        s_first, s_count = sample_range_of_rank(spp, rank, n_gpus)
+        acc = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
+        frame = torch.zeros((H, W, 3), dtype=torch.float32, device=dev) if rank == 0 else None
+        parallelism = f"spp split: {n_gpus} ranks x {s_count} samples + accumulator gather/sum on rank 0"
 
     def step():
-        if not distributed:
-            for c in my_chunks:
-                scene.render_chunk_device(settings, c, seed, frame.data_ptr(), None, W, c.left, c.top,
+        if args.mode == "tiles":
+            for row, c in comp.slots:   # each strip straight into the packed send buffer
+                scene.render_chunk_device(settings, c, seed, comp.packed[row:row + c.height].data_ptr(), None, W, 0, 0,
                                           counters.data_ptr(), stream)
-            return
-        row = 0
-        for c in my_chunks:   # render each strip straight into the packed send buffer
-            scene.render_chunk_device(settings, c, seed, packed[row:row + c.height].data_ptr(), None, W, 0, 0,
-                                      counters.data_ptr(), stream)
-            row += c.height
-        dist.gather(packed, gathered, dst=0)
-        if rank == 0:
-            for r in range(n_gpus):
-                row = 0
-                for i, c in enumerate(all_chunks):
-                    if i % n_gpus != r:
-                        continue
-                    frame[c.top:c.top + c.height] = gathered[r][row:row + c.height]
-                    row += c.height
+            comp.composite()
+        else:
+            acc.zero_()
+            if s_count:
+                scene.accumulate_chunk_device(settings, whole, seed, s_first, s_count, acc.data_ptr(), counters.data_ptr(), stream)
+            total = reduce_accumulators(acc, rank, n_gpus)
+            if rank == 0:
+                resolve_device(device, total.data_ptr(), W * H, spp, frame.data_ptr(), None, stream)
 
     def barrier():
         if distributed:
@@ -179,7 +169,7 @@ def main():
             "config": {"workload": args.workload, "scene": scene_name, "width": W, "height": H,
                        "samples_per_pixel": spp, "max_reflections": depth, "lens_radius": lens, "seed": seed,
                        "entities": int(info.entity_count), "triangles": int(info.instanced_triangle_count),
-                       "parallelism": "single GPU" if n_gpus == 1 else f"{8 * n_gpus} strips round-robin over {n_gpus} GPUs + RCCL gather to rank 0"},
+                       "parallelism": parallelism},
             "msamples_per_s": round(samples / elapsed / 1e6, 3),
             "rays_per_step": {"primary": primary // args.steps, "secondary": secondary // args.steps,
                               "shadow": shadow // args.steps},

@@ -220,6 +220,10 @@ const char* rt_last_error(void);
  * util.rs:6-28), flattens everything and uploads it to `device`.
  * Returns NULL on failure. */
 RtScene* rt_scene_create(const RtSceneDesc* desc, int device);
+/* device == RT_DEVICE_HOST_ONLY: validate and build the acceleration structures
+ * but upload nothing; such a scene only serves rt_scene_info / rt_scene_bvh_order
+ * (render entry points return RT_E_NO_DEVICE). */
+#define RT_DEVICE_HOST_ONLY (-1)
 void     rt_scene_destroy(RtScene* scene);
 
 /* Replaces the whole `for p in chunk.iter_pixels() { cast_rays_into_scene(..);

@@ -21,6 +21,7 @@ RT_MAT_LAMBERTIAN, RT_MAT_SPECULAR, RT_MAT_DIELECTRIC = 0, 1, 2
  RT_TEX_COLOR_MAP, RT_TEX_MESH, RT_TEX_MESH_SET) = range(7)
 RT_LIGHT_POINT, RT_LIGHT_LAMP, RT_LIGHT_DIRECTIONAL = 0, 1, 2
 RT_SKY_DAY, RT_SKY_BLACK = 0, 1
+RT_DEVICE_HOST_ONLY = -1
 
 
 class RtV3(C.Structure):

@@ -994,6 +994,7 @@ int upload(RtScene* s, const std::vector<T>& v, const T** dst) {
 
 int validate_call(const RtScene* scene, const RtSettings* st, const RtRenderChunk* ch) {
     if (!scene || !st || !ch) return set_error(RT_E_INVALID, "null argument");
+    if (scene->device == RT_DEVICE_HOST_ONLY) return set_error(RT_E_NO_DEVICE, "scene was created host-only (RT_DEVICE_HOST_ONLY): nothing to render on");
     if (st->width == 0 || st->height == 0 || st->samples_per_pixel == 0) return set_error(RT_E_INVALID, "RenderSettings: width, height and samples_per_pixel must be > 0");
     if (st->width > 65535 || st->height > 65535) return set_error(RT_E_LIMIT, "RenderSettings: image sides are limited to 65535 (RNG counter packs x | y<<16)");
     if (st->max_reflections > RT_MAX_REFLECTIONS) return set_error(RT_E_LIMIT, "RenderSettings: max_reflections is limited to 31 (recursion-tree node id is 32 bit)");
@@ -1065,6 +1066,14 @@ RtScene* rt_scene_create(const RtSceneDesc* desc, int device) {
     FlatScene flat; std::string err;
     int rc = build_flat_scene(desc, flat, err);
     if (rc) { set_error(rc, err); return nullptr; }
+    if (device == RT_DEVICE_HOST_ONLY) {
+        // acceleration structures only (rt_scene_info / rt_scene_bvh_order); nothing is uploaded
+        RtScene* s = new RtScene();
+        s->device = RT_DEVICE_HOST_ONLY;
+        s->info = flat.info;
+        s->tlas_order = std::move(flat.tlas_order); s->blas_order = std::move(flat.blas_order);
+        return s;
+    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { set_error(RT_E_NO_DEVICE, "no HIP device visible"); return nullptr; }
     if (device < 0 || device >= ndev) { set_error(RT_E_INVALID, "device index out of range"); return nullptr; }
@@ -1095,6 +1104,7 @@ RtScene* rt_scene_create(const RtSceneDesc* desc, int device) {
 
 void rt_scene_destroy(RtScene* s) {
     if (!s) return;
+    if (s->device == RT_DEVICE_HOST_ONLY) { delete s; return; }
     (void)hipSetDevice(s->device);
     if (s->stream) { (void)hipStreamSynchronize(s->stream); (void)hipStreamDestroy(s->stream); }
     for (void* p : s->allocations) (void)hipFree(p);
@@ -1215,7 +1225,7 @@ int rt_scene_profile_enable(RtScene* scene, int enable) {
 int rt_scene_profile_read(RtScene* scene, double* kernel_ms_total, uint64_t* launches) {
     if (!scene) return set_error(RT_E_INVALID, "null scene");
     std::lock_guard<std::mutex> g(scene->lock);
-    HIP_TRY(hipSetDevice(scene->device));
+    if (scene->device != RT_DEVICE_HOST_ONLY) HIP_TRY(hipSetDevice(scene->device));
     double total = 0.0;
     for (auto& ev : scene->profile_events) {
         HIP_TRY(hipEventSynchronize(ev.second));

@@ -1,0 +1,135 @@
+"""Host logic of the product on the CPU: scene construction, OBJ ingest,
+acceleration-structure build (against the oracle's independent build), scene
+validation and limits.  Uses RT_DEVICE_HOST_ONLY scenes: nothing is rendered."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from raytracer_amd import CameraConfiguration, RenderChunk, RenderSettings, RtError, Scene, SceneBuilder, _ffi, camera_new
+from tests.oracle import OracleScene
+
+SMALL = {"Doot Doot": {"Count": 3}, "Point Cloud": {"Cloud Point Count": 2000}}
+
+
+def sample(name, w=64, h=36):
+    return SceneBuilder.sample(name, CameraConfiguration(w, h), params=SMALL.get(name))
+
+
+def test_sample_scene_list():
+    names = SceneBuilder.sample_names()
+    for n in ("Random Spheres", "Mesh", "Dreadnaught", "Doot Doot", "Fleet", "Simple", "Planes", "Mirrors"):
+        assert n in names
+
+
+def test_weekend_scene_shape():
+    # raytracer-samples/src/samples.rs:108-183: ground + 3 big spheres + the grid cells
+    # that are not within 1.5 of a big sphere; one directional light; checker ground.
+    d = sample("Random Spheres").desc().contents
+    assert d.sky == _ffi.RT_SKY_DAY and d.light_count == 1 and d.plane_count == 0 and d.mesh_count == 0
+    assert d.entity_count == d.sphere_count and 4 + 22 * 22 - 40 < d.entity_count <= 4 + 22 * 22
+    assert d.spheres[0].radius == 1000.0 and d.translations[0].y == -1000.0
+    kinds = [d.materials[d.spheres[i].mat_id].kind for i in range(d.entity_count)]
+    assert kinds[1:4] == [_ffi.RT_MAT_LAMBERTIAN, _ffi.RT_MAT_DIELECTRIC, _ffi.RT_MAT_SPECULAR]
+    small = kinds[4:]
+    frac = [small.count(k) / len(small) for k in range(3)]
+    assert 0.7 < frac[0] < 0.9 and 0.08 < frac[1] < 0.22 and 0.01 < frac[2] < 0.1     # 80 / 15 / 5 %
+    for i in range(4, d.entity_count):
+        assert d.spheres[i].radius == np.float32(0.2) and d.translations[i].y == np.float32(0.2)
+
+
+@pytest.mark.parametrize("obj,tris", [("simple/cube.obj", 12), ("simple/plane.obj", 2), ("simple/thing.obj", 104),
+                                      ("simple/suzanne.obj", 968), ("Dreadnaught/Dreadnaught.obj", 4100),
+                                      ("skeleton/SKELETON.obj", 11101), ("Interceptor-T/Heavyinterceptor.obj", 300)])
+def test_obj_ingest_triangle_counts(obj, tris):
+    # counts of `f` lines of the reference's mesh assets
+    b = SceneBuilder(camera_new((0, 0, 5), (0, 0, 0), 45, 1.5, 0, 5), _ffi.RT_SKY_BLACK)
+    mesh, tex = b.load_obj(os.path.join(_ffi.ASSET_MESH_DIR, obj))
+    d = b.desc().contents
+    assert d.meshes[mesh].tri_count == tris
+    assert d.textures[tex].kind == _ffi.RT_TEX_MESH_SET
+
+
+def test_obj_ingest_cube_vertices_and_materials():
+    b = SceneBuilder(camera_new((0, 0, 5), (0, 0, 0), 45, 1.5, 0, 5), _ffi.RT_SKY_BLACK)
+    mesh, tex = b.load_obj(os.path.join(_ffi.ASSET_MESH_DIR, "simple/cube.obj"))
+    d = b.desc().contents
+    t0 = d.meshes[mesh].tris[0]                    # "f 5 3 1"
+    assert t0.a.tuple() == (-0.5, 1.0, -0.5) and t0.b.tuple() == (0.5, 1.0, 0.5) and t0.c.tuple() == (0.5, 1.0, -0.5)
+    assert t0.tex_key == -1                          # no usemtl -> None
+    assert d.textures[tex].child1 == 0               # empty MeshTextureSet
+    mesh, tex = b.load_obj(os.path.join(_ffi.ASSET_MESH_DIR, "skeleton/SKELETON.obj"))
+    d = b.desc().contents
+    ts = d.textures[tex]
+    assert ts.child1 == 1                            # one material: "WHITE BONE"
+    mt = d.textures[d.tex_set_entries[ts.child0]]
+    assert mt.kind == _ffi.RT_TEX_MESH and mt.color2.tuple() == (1.0, 1.0, 1.0)       # Ka
+    np.testing.assert_allclose(mt.color.tuple(), (0.6, 0.6, 0.4), rtol=1e-7)           # Kd
+    assert d.meshes[mesh].tris[0].tex_key == 0
+
+
+def test_obj_missing_file_is_an_error():
+    b = SceneBuilder(camera_new((0, 0, 5), (0, 0, 0), 45, 1.5, 0, 5), _ffi.RT_SKY_BLACK)
+    with pytest.raises(RtError, match="expected obj file"):
+        b.load_obj("/nonexistent/x.obj")
+    with pytest.raises(RtError, match="unknown sample scene"):
+        SceneBuilder.sample("No Such Scene", CameraConfiguration(8, 8))
+
+
+@pytest.mark.parametrize("name", ["Random Spheres", "Simple", "Planes", "Mirrors", "Triangles", "Mesh", "Mega Cube",
+                                  "Fleet", "Dreadnaught", "Doot Doot", "Point Cloud"])
+def test_bvh_build_matches_oracle(name):
+    """Two independent implementations of bvh.rs:129-188 + util.rs:6-28 (the product's
+    SoA/permutation builder and the oracle's restatement) must agree on the order in
+    which the reference would emit every object: that order decides exact ties."""
+    b = sample(name)
+    host = Scene(b, device=_ffi.RT_DEVICE_HOST_ONLY if hasattr(_ffi, "RT_DEVICE_HOST_ONLY") else -1)
+    orc = OracleScene(b)
+    d = b.desc().contents
+    order = host.bvh_order()
+    assert sorted(order.tolist()) == list(range(d.entity_count))
+    assert np.array_equal(order, orc.bvh_order())
+    info = host.info()
+    assert info.tlas_depth == orc.bvh_depth() - 1
+    for m in range(d.mesh_count):
+        assert np.array_equal(host.bvh_order(m), orc.bvh_order(m))
+    assert info.blas_depth == max([orc.bvh_depth(m) - 1 for m in range(d.mesh_count)], default=0)
+    assert info.triangle_count == sum(d.meshes[m].tri_count for m in range(d.mesh_count))
+
+
+def test_degenerate_leaf_is_split_without_losing_objects():
+    # 40 identical spheres: every split leaves one side empty (bvh.rs:169), the reference
+    # keeps one 40-object leaf; the product splits it into <= 8-object leaves with equal boxes
+    b = SceneBuilder(camera_new((0, 0, 5), (0, 0, 0), 45, 1.5, 0, 5), _ffi.RT_SKY_DAY)
+    m, t = b.add_lambertian(), b.add_color_texture((1, 0, 0))
+    for _ in range(40):
+        b.add_sphere_entity(1.0, m, t, translations=[(0, 0, 0)])
+    host, orc = Scene(b, device=-1), OracleScene(b)
+    assert np.array_equal(host.bvh_order(), orc.bvh_order())
+    assert orc.bvh_depth() == 1 and host.info().tlas_depth >= 3
+
+
+def test_scene_validation():
+    cam = camera_new((0, 0, 5), (0, 0, 0), 45, 1.5, 0, 5)
+    b = SceneBuilder(cam, _ffi.RT_SKY_DAY)
+    with pytest.raises(RtError, match="no entities"):
+        Scene(b, device=-1)
+    b.add_sphere_entity(1.0, 3, 0)                   # material 3 does not exist
+    with pytest.raises(RtError, match="out of range"):
+        Scene(b, device=-1)
+    b = SceneBuilder(cam, _ffi.RT_SKY_DAY)
+    m, c = b.add_lambertian(), b.add_color_texture((1, 1, 1))
+    chk = b.add_checker_texture(10.0, c, c)
+    bad = b.add_checker_texture(10.0, chk, c)        # nested checker: not representable
+    b.add_sphere_entity(1.0, m, bad)
+    with pytest.raises(RtError, match="checker"):
+        Scene(b, device=-1)
+
+
+def test_host_only_scene_cannot_render():
+    b = sample("Simple")
+    s = Scene(b, device=-1)
+    with pytest.raises(RtError) as e:
+        s.render_chunk(RenderSettings(8, 8, 5, 1), RenderChunk(0, 0, 8, 8))
+    assert e.value.code == _ffi.RT_E_NO_DEVICE
