@@ -26,7 +26,8 @@ def test_sample_scene_list():
 def test_weekend_scene_shape():
     # raytracer-samples/src/samples.rs:108-183: ground + 3 big spheres + the grid cells
     # that are not within 1.5 of a big sphere; one directional light; checker ground.
-    d = sample("Random Spheres").desc().contents
+    b = sample("Random Spheres")          # keep the builder alive: it owns the arrays
+    d = b.desc().contents
     assert d.sky == _ffi.RT_SKY_DAY and d.light_count == 1 and d.plane_count == 0 and d.mesh_count == 0
     assert d.entity_count == d.sphere_count and 4 + 22 * 22 - 40 < d.entity_count <= 4 + 22 * 22
     assert d.spheres[0].radius == 1000.0 and d.translations[0].y == -1000.0
