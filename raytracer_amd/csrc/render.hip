@@ -518,17 +518,20 @@ render_kernel(const DevSceneView S, const RenderParams P) {
     uint32_t* stack = lds_stack + threadIdx.x;
     const uint32_t stack_cap = S.stack_entries;
 
+    // Work items (pixel x sample segment) are dealt in blocks of 64 = one 8x8 pixel
+    // tile of one segment.  A wave owns one block at a time and all its lanes move on
+    // to the next block together, so the rays of a wave stay spatially coherent.
     const uint32_t total_items = P.pix_slots * P.seg_count;
-    const uint32_t stride = gridDim.x * blockDim.x;
-    uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t stride = gridDim.x * blockDim.x;                  // lanes in the grid = 64 * waves
+    uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;           // block base + lane
 
     uint32_t n_primary = 0, n_secondary = 0, n_shadow = 0, n_samples = 0;
 
     // Lane state between two rays.  PATH / SHADOW: a ray of that kind is in flight
     // (or, with `tracing` false, has just finished and waits for its shading).
-    enum { PATH = 0, SHADOW = 1, NEED_LIGHT = 2, NEED_PATH = 3, NEED_SAMPLE = 4, FINISHED = 5 };
-    int state = NEED_SAMPLE;
-    bool tracing = false, have_item = false;
+    enum { PATH = 0, SHADOW = 1, NEED_LIGHT = 2, NEED_PATH = 3, NEED_SAMPLE = 4, NEED_BLOCK = 5, FINISHED = 6 };
+    int state = NEED_BLOCK;
+    bool tracing = false;
     uint32_t px = 0, py = 0, s = 0, s_end = 0, out_slot = 0;
     F3 seg_sum = f3(0, 0, 0), sample_col = f3(0, 0, 0);
     Pending pend[RT_PENDING_MAX]; uint32_t npend = 0;
@@ -549,7 +552,31 @@ render_kernel(const DevSceneView S, const RenderParams P) {
     const DevNode* nodes = S.nodes;
 
     for (;;) {
-        if (!tracing) {
+        // ================= next block of work items: all lanes of the wave together ======
+        if (__ballot(state != NEED_BLOCK && state != FINISHED) == 0ull) {
+            if (state == NEED_BLOCK) {
+                if (item >= total_items) state = FINISHED;
+                else {
+                    const uint32_t seg_local = item / P.pix_slots, q = item % P.pix_slots;
+                    item += stride;
+                    const uint32_t tile = q >> 6, within = q & 63u;
+                    const uint32_t x = (tile % P.tiles_x) * 8u + (within & 7u), y = (tile / P.tiles_x) * 8u + (within >> 3);
+                    if (x < P.cw && y < P.ch) {       // lanes off the chunk's edge sit this block out
+                        const uint32_t seg = P.seg_first + seg_local;
+                        const uint32_t sa = seg * RT_SAMPLE_SEGMENT, sb = sa + RT_SAMPLE_SEGMENT;
+                        const uint32_t r_end = P.sample_first + P.sample_count;
+                        s = sa > P.sample_first ? sa : P.sample_first;
+                        s_end = sb < r_end ? sb : r_end;
+                        px = P.left + x; py = P.top + y;
+                        out_slot = seg_local * (P.cw * P.ch) + y * P.cw + x;
+                        seg_sum = f3(0.0f, 0.0f, 0.0f);
+                        state = NEED_SAMPLE;
+                    }
+                }
+            }
+            if (__ballot(state != FINISHED) == 0ull) break;      // the wave has no blocks left
+        }
+        if (!tracing && state != NEED_BLOCK && state != FINISHED) {
             // ================= shading of the ray that just finished =====================
             if (state == SHADOW) {
                 // cast_light_ray_to_lamp, implementation.rs:535-552
@@ -676,7 +703,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
             }
             // stage C: next sample / next work item
             while (state == NEED_SAMPLE) {
-                if (have_item && s < s_end) {
+                if (s < s_end) {
                     float lx = 0.0f, ly = 0.0f;
                     if (P.spp > 1) {                                                  // :648-653
                         float r0, r1; rng_pair(P.seed, px, py, s, 0u, PURPOSE_LENS, r0, r1);
@@ -692,29 +719,13 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                     } else state = PATH;
                     continue;
                 }
-                if (have_item) {
-                    float* out = P.partial + (uint64_t)out_slot * 3;
-                    out[0] = seg_sum.x; out[1] = seg_sum.y; out[2] = seg_sum.z;
-                    have_item = false;
-                }
-                if (item >= total_items) { state = FINISHED; break; }
-                const uint32_t seg_local = item / P.pix_slots, q = item % P.pix_slots;
-                item += stride;
-                const uint32_t tile = q >> 6, within = q & 63u;
-                const uint32_t x = (tile % P.tiles_x) * 8u + (within & 7u), y = (tile / P.tiles_x) * 8u + (within >> 3);
-                if (x >= P.cw || y >= P.ch) continue;
-                const uint32_t seg = P.seg_first + seg_local;
-                const uint32_t sa = seg * RT_SAMPLE_SEGMENT, sb = sa + RT_SAMPLE_SEGMENT;
-                const uint32_t r_end = P.sample_first + P.sample_count;
-                s = sa > P.sample_first ? sa : P.sample_first;
-                s_end = sb < r_end ? sb : r_end;
-                px = P.left + x; py = P.top + y;
-                out_slot = seg_local * (P.cw * P.ch) + y * P.cw + x;
-                seg_sum = f3(0.0f, 0.0f, 0.0f);
-                have_item = true;
+                // the item is done: store its segment sum and wait for the wave's next block
+                float* out = P.partial + (uint64_t)out_slot * 3;
+                out[0] = seg_sum.x; out[1] = seg_sum.y; out[2] = seg_sum.z;
+                state = NEED_BLOCK;
             }
             // ================= start the traversal of the new ray ==========================
-            if (state != FINISHED) {
+            if (state == PATH || state == SHADOW) {
                 const bool shadow = state == SHADOW;
                 o = shadow ? hp : ro;
                 d = shadow ? -ldir : rd;
@@ -728,7 +739,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                 tracing = true;
             }
         }
-        if (__ballot(tracing) == 0ull) break;      // every lane of the wave is FINISHED
+        if (__ballot(tracing) == 0ull) continue;   // nothing to traverse: the wave is between blocks
 
         // ================= traversal burst ===================================================
         // next deferred subtree; leaving a BLAS restores the world-space ray
@@ -863,7 +874,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
             }
             // leave the burst when enough lanes can take a new ray, or nobody is tracing
             const unsigned long long busy = __ballot(tracing);
-            const unsigned long long refill = __ballot(!tracing && state != FINISHED);
+            const unsigned long long refill = __ballot(!tracing && state != FINISHED && state != NEED_BLOCK);
             if (busy == 0ull || (uint32_t)__popcll(refill) >= P.refill_lanes) break;
         }
     }
