@@ -494,6 +494,7 @@ struct RenderParams {
     float* partial;                                 // [seg_count][cw*ch][3] segment sums
     unsigned long long* counters;                   // RtRayCounters on the device (nullable)
     uint32_t refill_lanes;                          // idle lanes that end a traversal burst
+    uint32_t* block_counter;                        // next unclaimed block of 64 work items (zeroed per launch)
 };
 
 __device__ __forceinline__ void gen_camera_ray(const DevSceneView& S, const RenderParams& P, uint32_t px, uint32_t py, float lx, float ly, F3& o, F3& d) {
@@ -521,9 +522,10 @@ render_kernel(const DevSceneView S, const RenderParams P) {
     // Work items (pixel x sample segment) are dealt in blocks of 64 = one 8x8 pixel
     // tile of one segment.  A wave owns one block at a time and all its lanes move on
     // to the next block together, so the rays of a wave stay spatially coherent.
+    // Blocks are claimed dynamically (one atomic per wave and block), so waves that
+    // drew cheap tiles simply take more of them.
     const uint32_t total_items = P.pix_slots * P.seg_count;
-    const uint32_t stride = gridDim.x * blockDim.x;                  // lanes in the grid = 64 * waves
-    uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;           // block base + lane
+    const uint32_t lane = threadIdx.x & 63u;
 
     uint32_t n_primary = 0, n_secondary = 0, n_shadow = 0, n_samples = 0;
 
@@ -555,10 +557,13 @@ render_kernel(const DevSceneView S, const RenderParams P) {
         // ================= next block of work items: all lanes of the wave together ======
         if (__ballot(state != NEED_BLOCK && state != FINISHED) == 0ull) {
             if (state == NEED_BLOCK) {
-                if (item >= total_items) state = FINISHED;
+                uint32_t blk = 0;
+                if (lane == 0) blk = atomicAdd(P.block_counter, 1u);
+                blk = __builtin_amdgcn_readfirstlane(blk);
+                const uint32_t item = blk * 64u + lane;
+                if (blk >= (total_items >> 6)) state = FINISHED;      // pix_slots is a multiple of 64
                 else {
                     const uint32_t seg_local = item / P.pix_slots, q = item % P.pix_slots;
-                    item += stride;
                     const uint32_t tile = q >> 6, within = q & 63u;
                     const uint32_t x = (tile % P.tiles_x) * 8u + (within & 7u), y = (tile / P.tiles_x) * 8u + (within >> 3);
                     if (x < P.cw && y < P.ch) {       // lanes off the chunk's edge sit this block out
@@ -1049,6 +1054,8 @@ int enqueue_accumulate(RtScene* scene, const RtSettings* st, const RtRenderChunk
         const uint64_t items = (uint64_t)P.pix_slots * bn;
         uint64_t blocks = (items + RT_BLOCK - 1) / RT_BLOCK;
         if (blocks > (uint64_t)scene->grid_blocks) blocks = scene->grid_blocks;
+        P.block_counter = (uint32_t*)((char*)scene->ctrl.p + 64);
+        HIP_TRY(hipMemsetAsync(P.block_counter, 0, sizeof(uint32_t), stream));
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
         if (scene->profiling) { HIP_TRY(hipEventCreate(&ev0)); HIP_TRY(hipEventCreate(&ev1)); HIP_TRY(hipEventRecord(ev0, stream)); }
         hipLaunchKernelGGL(render_kernel, dim3((uint32_t)blocks), dim3(RT_BLOCK), scene->lds_bytes, stream, scene->view, P);
