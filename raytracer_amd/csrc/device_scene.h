@@ -40,7 +40,7 @@ struct alignas(16) DevEntity { Word4 w[3]; };
 
 // ---- transforms: Word4 slots, per entity: n_trans translation slots
 // (x y z -) then per rotation 2 slots: (axis.x axis.y axis.z cos(-t))
-// (sin(-t) cos(+t) sin(+t) -).  sin/cos are evaluated once on the host with the
+// (sin(-t) cos(+t) sin(+t) identity-flag).  sin/cos are evaluated once on the host with the
 // same libm call the reference makes per ray (types.rs:200).
 
 // ---- mesh header (one BLAS) --------------------------------------------------

@@ -74,6 +74,16 @@ __device__ __forceinline__ bool is_zero(F3 a) { return a.x == 0.0f && a.y == 0.0
 __device__ __forceinline__ F3 rotate_cs(F3 p, F3 axis, float c, float s) {
     return (p * c) + (cross(axis, p) * s) + (axis * dot(axis, p) * (1.0f - c));
 }
+// A rotation whose host-evaluated cos is exactly 1 and sin exactly 0 maps p to
+// (p*1) + (cross*0) + (axis*dot*0) = p + (+-0) + (+-0), which is p itself, bit for
+// bit, whenever every component of p is finite, non-zero and far from overflow (a zero
+// component would take the sign of the zero terms; an infinite one would turn them into
+// NaN).  Only then is the arithmetic skipped; otherwise the full formula runs.
+__device__ __forceinline__ bool plain(float x) { const float a = fabsf(x); return a > 0.0f && a < 1.0e30f; }
+__device__ __forceinline__ F3 rotate_cs_id(F3 p, F3 axis, float c, float s, bool identity) {
+    if (identity && plain(p.x) && plain(p.y) && plain(p.z)) return p;
+    return rotate_cs(p, axis, c, s);
+}
 __device__ __forceinline__ F3 ld3(const float* p) { return f3(p[0], p[1], p[2]); }
 __device__ __forceinline__ F3 w3(const Word4& w) { return f3(w.f[0], w.f[1], w.f[2]); }
 
@@ -160,8 +170,8 @@ __device__ __forceinline__ void ray_to_entity(const DevSceneView& S, const Word4
     for (uint32_t k = 0; k < n_rot; k++) {
         const Word4 a = ldw(x + 2 * k), b = ldw(x + 2 * k + 1);
         const F3 axis = w3(a);
-        o = rotate_cs(o, axis, a.f[3], b.f[0]);      // cos(-theta), sin(-theta)
-        d = rotate_cs(d, axis, a.f[3], b.f[0]);
+        o = rotate_cs_id(o, axis, a.f[3], b.f[0], b.u[3] != 0u);      // cos(-theta), sin(-theta)
+        d = rotate_cs_id(d, axis, a.f[3], b.f[0], b.u[3] != 0u);
     }
 }
 
@@ -355,8 +365,8 @@ __device__ __forceinline__ void resolve_hit(const DevSceneView& S, F3 o, F3 d, c
         const Word4* x = S.xforms + e1.u[2];
         for (uint32_t k = n_rot; k-- > 0;) {
             const Word4 a = ldw(x + n_trans + 2 * k), b = ldw(x + n_trans + 2 * k + 1);
-            p = rotate_cs(p, w3(a), b.f[1], b.f[2]);
-            normal = rotate_cs(normal, w3(a), b.f[1], b.f[2]);
+            p = rotate_cs_id(p, w3(a), b.f[1], b.f[2], b.u[3] != 0u);
+            normal = rotate_cs_id(normal, w3(a), b.f[1], b.f[2], b.u[3] != 0u);
         }
         for (uint32_t k = n_trans; k-- > 0;) p = p + w3(ldw(x + k));
     }
@@ -497,10 +507,13 @@ struct RenderParams {
     uint32_t* block_counter;                        // next unclaimed block of 64 work items (zeroed per launch)
 };
 
-__device__ __forceinline__ void gen_camera_ray(const DevSceneView& S, const RenderParams& P, uint32_t px, uint32_t py, float lx, float ly, F3& o, F3& d) {
-    // cast_rays_into_scene :645-646 + Camera::get_ray :482-491
-    const float u = (float)px / (float)P.width;
-    const float v = (float)(P.height - py) / (float)P.height;
+// cast_rays_into_scene :645-646: the same two values for every sample of a pixel
+__device__ __forceinline__ void pixel_uv(const RenderParams& P, uint32_t px, uint32_t py, float& u, float& v) {
+    u = (float)px / (float)P.width;
+    v = (float)(P.height - py) / (float)P.height;
+}
+__device__ __forceinline__ void gen_camera_ray(const DevSceneView& S, float u, float v, float lx, float ly, F3& o, F3& d) {
+    // Camera::get_ray :482-491
     const float ldx = lx * S.cam_lens_radius, ldy = ly * S.cam_lens_radius;
     const F3 offset = (ld3(S.cam_u) * ldx) + (ld3(S.cam_v) * ldy);
     o = ld3(S.cam_origin) + offset;
@@ -535,6 +548,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
     int state = NEED_BLOCK;
     bool tracing = false;
     uint32_t px = 0, py = 0, s = 0, s_end = 0, out_slot = 0;
+    float pu = 0.0f, pv = 0.0f;
     F3 seg_sum = f3(0, 0, 0), sample_col = f3(0, 0, 0);
     Pending pend[RT_PENDING_MAX]; uint32_t npend = 0;
     F3 ro = f3(0, 0, 0), rd = f3(0, 0, 1), rw = f3(0, 0, 0); uint32_t rlimit = 0, rnode = 0;   // current path ray
@@ -573,6 +587,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                         s = sa > P.sample_first ? sa : P.sample_first;
                         s_end = sb < r_end ? sb : r_end;
                         px = P.left + x; py = P.top + y;
+                        pixel_uv(P, px, py, pu, pv);
                         out_slot = seg_local * (P.cw * P.ch) + y * P.cw + x;
                         seg_sum = f3(0.0f, 0.0f, 0.0f);
                         state = NEED_SAMPLE;
@@ -714,7 +729,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                         float r0, r1; rng_pair(P.seed, px, py, s, 0u, PURPOSE_LENS, r0, r1);
                         lx = r0 * 2.0f - 1.0f; ly = r1 * 2.0f - 1.0f;
                     }
-                    gen_camera_ray(S, P, px, py, lx, ly, ro, rd);
+                    gen_camera_ray(S, pu, pv, lx, ly, ro, rd);
                     rw = f3(1.0f, 1.0f, 1.0f); rlimit = P.max_reflections; rnode = 1u;
                     sample_col = f3(0.0f, 0.0f, 0.0f); npend = 0; n_samples++;
                     if (rlimit == 0) {                                                // :562-564: sky, no ray cast
@@ -941,7 +956,9 @@ primary_kernel(const DevSceneView S, const RenderParams P, float* t_out, float* 
     if (i >= P.cw * P.ch) return;
     const uint32_t x = i % P.cw, y = i / P.cw;
     F3 o, d;
-    gen_camera_ray(S, P, P.left + x, P.top + y, 0.0f, 0.0f, o, d);
+    float pu, pv;
+    pixel_uv(P, P.left + x, P.top + y, pu, pv);
+    gen_camera_ray(S, pu, pv, 0.0f, 0.0f, o, d);
     Hit h;
     trace(S, o, d, RT_BIAS, RT_F32_MAX, stack, S.stack_entries, h);
     float t = -1.0f; F3 n = f3(0, 0, 0); int32_t e = -1, tri = -1;

@@ -373,7 +373,11 @@ int build_flat_scene(const RtSceneDesc* d, FlatScene& out, std::string& err) {
             const RtRotation& r = d->rotations[e.rotation_first + k];
             Word4 w0, w1;
             w0.f[0] = r.axis.x; w0.f[1] = r.axis.y; w0.f[2] = r.axis.z; w0.f[3] = cosf(-r.theta);
-            w1.f[0] = sinf(-r.theta); w1.f[1] = cosf(r.theta); w1.f[2] = sinf(r.theta); w1.f[3] = 0.0f;
+            w1.f[0] = sinf(-r.theta); w1.f[1] = cosf(r.theta); w1.f[2] = sinf(r.theta);
+            // exact identity (see rotate_cs_id in render.hip): both directions, tame axis
+            const bool identity = w0.f[3] == 1.0f && w1.f[0] == 0.0f && w1.f[1] == 1.0f && w1.f[2] == 0.0f &&
+                                  fabsf(r.axis.x) <= 2.0f && fabsf(r.axis.y) <= 2.0f && fabsf(r.axis.z) <= 2.0f;
+            w1.u[3] = identity ? 1u : 0u;
             out.xforms.push_back(w0); out.xforms.push_back(w1);
         }
     }
