@@ -15,10 +15,10 @@ quoted on): raytracer-samples "Random Spheres" (the `weekend` scene), 1920x1080,
 256 spp, max depth 8, lens radius 0.1, seed 12345.  `--workload` selects the
 other BASELINE configs (they are parity/diagnostic cases, not the default line).
 
-N > 1: the image is cut into horizontal strips with create_render_chunks
-(viewport.rs:30-54), dealt round-robin to the ranks; every rank renders its
-strips into device memory and rank 0 gathers them over RCCL/xGMI (one exchange
-per frame).  The frame is fixed, so scaling is "strong".
+N > 1: the image is cut into 8-row strips (create_render_chunks(size,[1,n]),
+viewport.rs:30-54), dealt round-robin to the ranks; every rank renders all its
+strips in one launch into device memory and rank 0 gathers them over RCCL/xGMI
+(one exchange per frame).  The frame is fixed, so scaling is "strong".
 
 The JSON line also carries
   roofline     : the render kernel against the f32 VALU peak (the path is f32
@@ -80,7 +80,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    distributed = "RANK" in os.environ and "MASTER_ADDR" in os.environ     # launched by torch.distributed.run
     if distributed:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -99,15 +99,15 @@ def main():
     info = scene.info()
 
     # ---- work split ---------------------------------------------------------
-    from raytracer_amd.dist import StripCompositor, reduce_accumulators, sample_range_of_rank, strip_chunks
+    from raytracer_amd.dist import InterleavedCompositor, reduce_accumulators, sample_range_of_rank
     from raytracer_amd import resolve_device
     counters = torch.zeros(4, dtype=torch.int64, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
     whole = RenderChunk(0, 0, W, H)
     if args.mode == "tiles":
-        chunks = [whole] if n_gpus == 1 else strip_chunks(W, H, n_gpus)
-        comp = StripCompositor(W, H, chunks, rank, n_gpus, dev)
-        parallelism = "single GPU" if n_gpus == 1 else f"{len(chunks)} strips round-robin over {n_gpus} GPUs + RCCL gather to rank 0"
+        comp = InterleavedCompositor(W, H, rank, n_gpus, dev, strip_height=8)
+        parallelism = ("single GPU" if n_gpus == 1 else
+                       f"8-row strips dealt round-robin over {n_gpus} GPUs, one launch per GPU, RCCL gather to rank 0")
     else:
         s_first, s_count = sample_range_of_rank(spp, rank, n_gpus)
         acc = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
@@ -116,10 +116,13 @@ def main():
 
     def step():
         if args.mode == "tiles":
-            for row, c in comp.slots:   # each strip straight into the packed send buffer
-                scene.render_chunk_device(settings, c, seed, comp.packed[row:row + c.height].data_ptr(), None, W, 0, 0,
+            if n_gpus == 1:
+                scene.render_chunk_device(settings, whole, seed, comp.packed.data_ptr(), None, W, 0, 0,
                                           counters.data_ptr(), stream)
-            comp.composite()
+            else:           # all of this rank's strips in one launch, straight into the send buffer
+                scene.render_strips_device(settings, comp.strip_height, rank, n_gpus, seed, comp.packed.data_ptr(), None,
+                                           counters.data_ptr(), stream)
+                comp.composite()
         else:
             acc.zero_()
             if s_count:

@@ -254,6 +254,21 @@ int rt_render_chunk_device(RtScene* scene, const RtSettings* settings,
                            uint32_t pitch_pixels, uint32_t out_x, uint32_t out_y,
                            void* counters_dev, void* stream);
 
+/* Tile-partitioned rendering for one of N GPUs (partitioning 1).
+ * Replaces the shared chunk queue of the reference's worker threads
+ * (src/render.rs:186-224, 63-78): the frame is cut into horizontal strips of
+ * `strip_height` rows (create_render_chunks(size,[1,n]) with equal strips) and this
+ * call renders, in ONE launch, the strips strip_first, strip_first+strip_period, ...
+ * Outputs (device pointers, nullable) are PACKED: rt_strip_rows() rows of
+ * settings.width pixels, the owned strips one after the other.  Pixels are
+ * identical to those of rt_render_chunk for the same image rows. */
+int rt_render_strips_device(RtScene* scene, const RtSettings* settings,
+                            uint32_t strip_height, uint32_t strip_first, uint32_t strip_period,
+                            uint64_t seed, void* rgb_dev, void* rgba_dev,
+                            void* counters_dev, void* stream);
+/* Rows owned by (strip_first, strip_period) in an image of `height` rows; < 0 on bad arguments. */
+int rt_strip_rows(uint32_t height, uint32_t strip_height, uint32_t strip_first, uint32_t strip_period);
+
 /* spp-split rendering (partitioning 2): adds the SUM of the
  * per-sample clamped colours (implementation.rs:635,656) of samples
  * [sample_first, sample_first+sample_count) to accum_dev (float3 per pixel,

@@ -505,6 +505,7 @@ struct RenderParams {
     unsigned long long* counters;                   // RtRayCounters on the device (nullable)
     uint32_t refill_lanes;                          // idle lanes that end a traversal burst
     uint32_t* block_counter;                        // next unclaimed block of 64 work items (zeroed per launch)
+    uint32_t strip_h, strip_period_rows, strip_first_row;   // strip_h != 0: local row y -> image row (interleaved strips)
 };
 
 // cast_rays_into_scene :645-646: the same two values for every sample of a pixel
@@ -586,7 +587,8 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                         const uint32_t r_end = P.sample_first + P.sample_count;
                         s = sa > P.sample_first ? sa : P.sample_first;
                         s_end = sb < r_end ? sb : r_end;
-                        px = P.left + x; py = P.top + y;
+                        px = P.left + x;
+                        py = P.strip_h ? P.strip_first_row + (y / P.strip_h) * P.strip_period_rows + (y % P.strip_h) : P.top + y;
                         pixel_uv(P, px, py, pu, pv);
                         out_slot = seg_local * (P.cw * P.ch) + y * P.cw + x;
                         seg_sum = f3(0.0f, 0.0f, 0.0f);
@@ -1038,9 +1040,11 @@ int validate_call(const RtScene* scene, const RtSettings* st, const RtRenderChun
 
 // Enqueue: accumulate the sum of clamped samples [first, first+count) of the chunk
 // into `acc` (float3 image with pitch acc_pitch, chunk origin at acc_x/acc_y).
+struct Interleave { uint32_t strip_h = 0, period_rows = 0, first_row = 0; };
+
 int enqueue_accumulate(RtScene* scene, const RtSettings* st, const RtRenderChunk* ch, uint64_t seed, uint32_t sample_first,
                        uint32_t sample_count, float* acc, uint32_t acc_pitch, uint32_t acc_x, uint32_t acc_y, bool init_zero,
-                       unsigned long long* counters_dev, hipStream_t stream) {
+                       unsigned long long* counters_dev, hipStream_t stream, Interleave il = Interleave()) {
     if (sample_count == 0 || (uint64_t)sample_first + sample_count > st->samples_per_pixel) return set_error(RT_E_INVALID, "sample range outside samples_per_pixel");
     const uint32_t npix = ch->width * ch->height;
     const uint32_t seg_lo = sample_first / RT_SAMPLE_SEGMENT;
@@ -1061,6 +1065,7 @@ int enqueue_accumulate(RtScene* scene, const RtSettings* st, const RtRenderChunk
     P.pix_slots = P.tiles_x * ((ch->height + 7) / 8) * 64;
     P.partial = (float*)scene->partial.p;
     P.counters = counters_dev;
+    P.strip_h = il.strip_h; P.strip_period_rows = il.period_rows; P.strip_first_row = il.first_row;
     {
         static const uint32_t refill = []() { const char* e = getenv("RT_REFILL_LANES"); int v = e ? atoi(e) : RT_REFILL_LANES; return (uint32_t)(v < 1 ? 1 : (v > 64 ? 64 : v)); }();
         P.refill_lanes = refill;
@@ -1189,6 +1194,39 @@ int rt_render_chunk(RtScene* scene, const RtSettings* st, const RtRenderChunk* c
     HIP_TRY(hipMemcpyAsync(&c, scene->ctrl.p, sizeof(c), hipMemcpyDeviceToHost, scene->stream));
     HIP_TRY(hipStreamSynchronize(scene->stream));
     if (counters) { counters->primary += c.primary; counters->secondary += c.secondary; counters->shadow += c.shadow; counters->samples += c.samples; }
+    return RT_OK;
+}
+
+int rt_strip_rows(uint32_t height, uint32_t strip_height, uint32_t strip_first, uint32_t strip_period) {
+    if (strip_height == 0 || strip_period == 0 || strip_first >= strip_period) return RT_E_INVALID;
+    uint64_t rows = 0;
+    for (uint64_t top = (uint64_t)strip_first * strip_height; top < height; top += (uint64_t)strip_period * strip_height)
+        rows += (height - top < strip_height) ? height - top : strip_height;
+    return (int)rows;
+}
+
+int rt_render_strips_device(RtScene* scene, const RtSettings* st, uint32_t strip_height, uint32_t strip_first, uint32_t strip_period,
+                            uint64_t seed, void* rgb_dev, void* rgba_dev, void* counters_dev, void* stream) {
+    if (!st) return set_error(RT_E_INVALID, "null argument");
+    const int rows = rt_strip_rows(st->height, strip_height, strip_first, strip_period);
+    if (rows < 0) return set_error(RT_E_INVALID, "rt_render_strips_device: strip_height and strip_period must be > 0, strip_first < strip_period");
+    if (rows == 0) return RT_OK;                         // this rank owns no rows of so small an image
+    RtRenderChunk local{0, 0, st->width, (uint32_t)rows};   // packed local rows; validated against a frame that tall
+    RtSettings probe = *st; probe.height = probe.height > (uint32_t)rows ? probe.height : (uint32_t)rows;
+    int rc = validate_call(scene, &probe, &local);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> g(scene->lock);
+    HIP_TRY(hipSetDevice(scene->device));
+    hipStream_t sm = (hipStream_t)stream;
+    const uint32_t npix = local.width * local.height;
+    if ((rc = scene->accum.ensure((size_t)npix * 12))) return rc;
+    Interleave il; il.strip_h = strip_height; il.period_rows = strip_period * strip_height; il.first_row = strip_first * strip_height;
+    rc = enqueue_accumulate(scene, st, &local, seed, 0, st->samples_per_pixel, (float*)scene->accum.p, local.width, 0, 0, true,
+                            (unsigned long long*)counters_dev, sm, il);
+    if (rc) return rc;
+    hipLaunchKernelGGL(finish_kernel, dim3((npix + 255) / 256), dim3(256), 0, sm, (const float*)scene->accum.p, local.width, 0u, 0u, local.width, npix,
+                       (float)st->samples_per_pixel, (float*)rgb_dev, (uint8_t*)rgba_dev, local.width, 0u, 0u);
+    HIP_TRY(hipGetLastError());
     return RT_OK;
 }
 

@@ -29,6 +29,19 @@ from .scene import create_render_chunks
 SAMPLE_SEGMENT = 32   # RT_SAMPLE_SEGMENT of csrc/render.hip
 
 
+def _gather(tensor, gather_list, dst, rank, world):
+    """dist.gather, or (backends without it) all_gather keeping only rank dst's copy."""
+    try:
+        dist.gather(tensor, gather_list, dst=dst)
+        return gather_list
+    except (NotImplementedError, RuntimeError) as e:
+        if "gather" not in str(e).lower() and "support" not in str(e).lower():
+            raise
+        everywhere = [torch.zeros_like(tensor) for _ in range(world)]
+        dist.all_gather(everywhere, tensor)
+        return everywhere if rank == dst else None
+
+
 def strip_chunks(width, height, world, strips_per_rank=8):
     """The frame as `world * strips_per_rank` horizontal strips (fewer if the image
     is shorter), in create_render_chunks order."""
@@ -68,11 +81,11 @@ class StripCompositor:
 
     def composite(self):
         """One exchange: afterwards rank `dst` holds the whole frame in .frame."""
+        sources = [self.packed]
         if self.world > 1:
-            dist.gather(self.packed, self.gathered, dst=self.dst)
+            sources = _gather(self.packed, self.gathered, self.dst, self.rank, self.world)
         if self.rank != self.dst:
             return None
-        sources = self.gathered if self.world > 1 else [self.packed]
         for r in range(self.world):
             row = 0
             for c in chunks_of_rank(self.chunks, r, self.world):
@@ -81,12 +94,53 @@ class StripCompositor:
         return self.frame
 
 
+class InterleavedCompositor:
+    """Fine-grained tile partition: the frame is cut into strips of `strip_height`
+    rows (a multiple of 8 keeps the kernel's 8x8 ray tiles inside one strip) and rank r
+    owns strips r, r+world, r+2*world, ...  The rank renders ALL of them in one launch
+    (rt_render_strips_device) into `.packed`; one gather later rank `dst` scatters the
+    rows into `.frame` with a precomputed row index."""
+
+    def __init__(self, width, height, rank, world, device, strip_height=8, channels=3, dtype=torch.float32, dst=0):
+        from .scene import strip_rows
+        self.width, self.height, self.rank, self.world, self.dst, self.strip_height = width, height, rank, world, dst, strip_height
+        self.rows = [strip_rows(height, strip_height, r, world) for r in range(world)]
+        assert sum(self.rows) == height
+        self.my_rows = self.rows[rank]
+        self.packed = torch.zeros((max(max(self.rows), 1), width, channels), dtype=dtype, device=device)
+        self.gathered = ([torch.zeros_like(self.packed) for _ in range(world)] if rank == dst and world > 1 else None)
+        self.frame = torch.zeros((height, width, channels), dtype=dtype, device=device) if rank == dst else None
+        self.row_index = None
+        if rank == dst:
+            self.row_index = [torch.tensor(self.image_rows(r), dtype=torch.long, device=device) for r in range(world)]
+
+    def image_rows(self, r):
+        """Image row of every packed local row of rank r."""
+        h, out = self.strip_height, []
+        top = r * h
+        while top < self.height:
+            out.extend(range(top, min(top + h, self.height)))
+            top += self.world * h
+        return out
+
+    def composite(self):
+        sources = [self.packed]
+        if self.world > 1:
+            sources = _gather(self.packed, self.gathered, self.dst, self.rank, self.world)
+        if self.rank != self.dst:
+            return None
+        for r in range(self.world):
+            if self.rows[r]:
+                self.frame.index_copy_(0, self.row_index[r], sources[r][:self.rows[r]])
+        return self.frame
+
+
 def reduce_accumulators(acc, rank, world, dst=0):
     """Sum the per-rank accumulators onto rank `dst` in rank order (deterministic)."""
     if world == 1:
         return acc
     gathered = [torch.zeros_like(acc) for _ in range(world)] if rank == dst else None
-    dist.gather(acc, gathered, dst=dst)
+    gathered = _gather(acc, gathered, dst, rank, world)
     if rank != dst:
         return None
     total = gathered[0].clone()

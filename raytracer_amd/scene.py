@@ -290,6 +290,12 @@ class Scene:
         self._check(self._lib.rt_render_chunk_device(self._h, C.byref(settings.c), C.byref(chunk), seed, rgb_ptr,
                                                      rgba_ptr, pitch_pixels, out_x, out_y, counters_ptr, stream))
 
+    def render_strips_device(self, settings, strip_height, strip_first, strip_period, seed, rgb_ptr, rgba_ptr,
+                             counters_ptr=None, stream=None):
+        """Every strip_period-th strip of the frame, one launch, packed output rows."""
+        self._check(self._lib.rt_render_strips_device(self._h, C.byref(settings.c), strip_height, strip_first,
+                                                      strip_period, seed, rgb_ptr, rgba_ptr, counters_ptr, stream))
+
     def accumulate_chunk_device(self, settings, chunk, seed, sample_first, sample_count, accum_ptr,
                                 counters_ptr=None, stream=None):
         self._check(self._lib.rt_accumulate_chunk_device(self._h, C.byref(settings.c), C.byref(chunk), seed,
@@ -314,6 +320,13 @@ class Scene:
         self._check(self._lib.rt_primary_hits(self._h, C.byref(settings.c), C.byref(chunk), t.ctypes.data,
                                               n.ctypes.data, e.ctypes.data, tri.ctypes.data))
         return t, n, e, tri
+
+
+def strip_rows(height, strip_height, strip_first, strip_period):
+    n = _ffi.load_hip().rt_strip_rows(height, strip_height, strip_first, strip_period)
+    if n < 0:
+        raise RtError(n, "bad strip arguments")
+    return n
 
 
 def resolve_device(device, accum_ptr, n_pixels, samples_per_pixel, rgb_ptr, rgba_ptr, stream=None):

@@ -87,3 +87,49 @@ def test_partition_helpers():
                     assert f == pos and f % 32 == 0
                     pos += c
     assert len(strip_chunks(64, 5, 8)) == 5        # never more strips than rows
+
+
+def _worker_interleaved(rank, world, port, result_path):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from raytracer_amd import CameraConfiguration, RenderChunk, RenderSettings, SceneBuilder
+        from raytracer_amd.dist import InterleavedCompositor
+        from tests.oracle import ORC_RNG_COUNTER, OracleScene
+        b = SceneBuilder.sample("Random Spheres", CameraConfiguration(W, H))
+        o = OracleScene(b)
+        st = RenderSettings(W, H, DEPTH, 3)
+        comp = InterleavedCompositor(W, H, rank, world, torch.device("cpu"), strip_height=8)
+        rows = comp.image_rows(rank)
+        assert len(rows) == comp.my_rows
+        # the oracle stands in for rt_render_strips_device: strip by strip into packed rows
+        i = 0
+        while i < len(rows):
+            n = 1
+            while i + n < len(rows) and rows[i + n] == rows[i] + n:
+                n += 1
+            rgb, _, _ = o.render_chunk(st, RenderChunk(0, rows[i], W, n), ORC_RNG_COUNTER, SEED)
+            comp.packed[i:i + n] = torch.from_numpy(rgb)
+            i += n
+        frame = comp.composite()
+        if rank == 0:
+            full, _, _ = o.render_chunk(st, RenderChunk(0, 0, W, H), ORC_RNG_COUNTER, SEED)
+            np.save(result_path, np.array([float(np.array_equal(frame.numpy(), full))]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_gloo_interleaved_strips(tmp_path):
+    result = str(tmp_path / "ok.npy")
+    mp.spawn(_worker_interleaved, args=(2, _free_port(), result), nprocs=2, join=True)
+    assert np.load(result)[0] == 1.0
+
+
+def test_strip_rows_cover_the_image():
+    sys.path.insert(0, ROOT)
+    from raytracer_amd import strip_rows
+    for h in (1, 5, 26, 1080, 2160):
+        for world in (1, 2, 3, 8):
+            for sh in (8, 16):
+                assert sum(strip_rows(h, sh, r, world) for r in range(world)) == h
