@@ -46,7 +46,7 @@ if ROOT not in sys.path:
 # per-op flop costs fixed from the reference arithmetic
 F_AABB, F_SPH, F_TRI, F_PLANE, F_XFORM, F_SHADE = 27, 40, 90, 30, 45, 150
 # bytes touched per visit in the HBM layout of device_scene.h
-B_NODE, B_ENTITY, B_TRI, B_INST, B_RAY, B_PIXEL = 32, 48, 48, 48 + 32, 24, 12
+B_NODE, B_ENTITY, B_TRI, B_INST, B_RAY, B_PIXEL = 32, 48, 48, 48 + 48, 24, 12
 VALU_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 vector
 HBM_PEAK_GBS = 8000.0
 
@@ -195,14 +195,19 @@ def main():
         hits_per_ray = (cn_s.rays.primary + cn_s.rays.secondary) / r_s          # shading happens per path ray
         flops_per_ray = (per_ray["nodes"] * F_AABB + per_ray["spheres"] * F_SPH + per_ray["planes"] * F_PLANE +
                          per_ray["tris"] * F_TRI + per_ray["xforms"] * F_XFORM + hits_per_ray * F_SHADE)
-        bytes_per_ray = (per_ray["nodes"] * B_NODE + (per_ray["spheres"] + per_ray["planes"]) * B_ENTITY +
-                         per_ray["tris"] * B_TRI + per_ray["instances"] * B_INST + B_RAY) + B_PIXEL * (samples / max(rays, 1)) / spp
+        # on-chip gather demand per ray in the HBM layout (served by L1/L2 for these scenes)
+        gather_bytes_per_ray = (per_ray["nodes"] * B_NODE + (per_ray["spheres"] + per_ray["planes"]) * B_ENTITY +
+                                per_ray["tris"] * B_TRI + per_ray["instances"] * B_INST + B_RAY)
         kernel_s = kernel_ms / 1e3 / max(launches, 1)
         rays_per_launch = rays / max(launches, 1)
         tflops = flops_per_ray * rays_per_launch / kernel_s / 1e12
-        gbs = bytes_per_ray * rays_per_launch / kernel_s / 1e9
+        # algorithmic HBM bytes of one launch: the scene once + one float3 segment sum per work item
+        from raytracer_amd import sample_segment
+        segs = (spp + sample_segment() - 1) // sample_segment()
+        hbm_bytes_per_launch = (int(info.device_bytes) + W * H * segs * B_PIXEL) * (args.steps / max(launches, 1))
+        gbs = hbm_bytes_per_launch / kernel_s / 1e9
         traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # written by tools/pmc_traffic.py from rocprofv3 --pmc passes
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # HBM bytes per launch from rocprofv3 --pmc passes
         if os.path.exists(pmc_path):
             try:
                 traffic = json.load(open(pmc_path)).get(args.workload)
@@ -216,10 +221,13 @@ def main():
             "per_ray": {k: round(v, 3) for k, v in per_ray.items()}, "traversal_mismatch": int(cn_s.min_mismatch),
         }
         result["roofline_hbm"] = {"bound": "hbm", "achieved": round(gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                  "frac": round(gbs / HBM_PEAK_GBS, 6), "bytes_per_ray": round(bytes_per_ray, 2),
-                                  "scene_bytes": int(info.device_bytes)}
+                                  "frac": round(gbs / HBM_PEAK_GBS, 6), "bytes_per_launch": int(hbm_bytes_per_launch),
+                                  "scene_bytes": int(info.device_bytes),
+                                  "on_chip_gather_bytes_per_ray": round(gather_bytes_per_ray, 2),
+                                  "on_chip_gather_GBps": round(gather_bytes_per_ray * rays_per_launch / kernel_s / 1e9, 1)}
         # (2) the reference's multithreaded CPU path, bounded sample of the same frame
-        stride = args.cpu_chunk_stride or max(1, int(round(n_chunks * (spp / 256.0) * (W * H / (1920.0 * 1080.0)) / 300.0)))
+        # about 6e8 samples (10-20 s on 16 host threads)
+        stride = args.cpu_chunk_stride or max(1, int(round(W * H * spp / 6.0e8)))
         count = (n_chunks - 1) // stride
         cn_b, ms_b = oracle.render_chunks_mt(settings, grid, 0, stride, count, threads, rng_mode=ORC_RNG_XORSHIFT_CHUNK,
                                              seed=seed)

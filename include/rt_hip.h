@@ -307,6 +307,12 @@ int rt_create_render_chunks(uint32_t width, uint32_t height,
 /* v3_to_rgba (src/rgba.rs:6-12) on the host, for callers that kept floats. */
 void rt_v3_to_rgba(const float* rgb, uint64_t n_pixels, uint8_t* rgba_out);
 
+/* The fixed summation order of the samples of a pixel: sequential inside segments
+ * of this many consecutive sample indices, then the segment sums in index order
+ * (implementation.rs:641-659 sums all samples sequentially; identical for
+ * samples_per_pixel <= the segment).  spp-split ranges should fall on multiples. */
+uint32_t rt_sample_segment(void);
+
 /* Introspection used by tests and the bench (no reference counterpart). */
 typedef struct RtSceneInfo {
     uint64_t entity_count;

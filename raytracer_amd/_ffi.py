@@ -159,6 +159,7 @@ HIP_PROTOTYPES = {
                                          C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
     "rt_render_strips_device": (C.c_int, [C.c_void_p, _P(RtSettings), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rt_sample_segment": (C.c_uint32, []),
     "rt_strip_rows": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "rt_accumulate_chunk_device": (C.c_int, [C.c_void_p, _P(RtSettings), _P(RtRenderChunk), C.c_uint64, C.c_uint32,
                                              C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),

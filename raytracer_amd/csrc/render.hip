@@ -39,9 +39,14 @@
 
 // Samples of one pixel are summed sequentially inside segments of this many
 // consecutive sample indices, and the segment sums sequentially in index order.
-// (implementation.rs:641-659 sums all samples sequentially; for spp <= 32 the
-// two are the same order.)  Fixed so that results do not depend on launch shape.
-#define RT_SAMPLE_SEGMENT 32u
+// (implementation.rs:641-659 sums all samples sequentially; for spp <= the segment
+// the two are the same order.)  Fixed, so results do not depend on launch shape.
+// A work item is one pixel x one segment: 8 measured best on MI355X (32 / 16 / 8 / 4:
+// 57.4 / 53.5 / 52.7 / 56.9 ms for the weekend 1080p 256 spp frame; smaller items
+// shorten the tail of a launch, larger ones amortise the per-item set-up).
+#ifndef RT_SAMPLE_SEGMENT
+#define RT_SAMPLE_SEGMENT 8u
+#endif
 #define RT_BLOCK 256
 #define RT_PENDING_MAX 8
 #ifndef RT_WAVES_PER_SIMD
@@ -1196,6 +1201,8 @@ int rt_render_chunk(RtScene* scene, const RtSettings* st, const RtRenderChunk* c
     if (counters) { counters->primary += c.primary; counters->secondary += c.secondary; counters->shadow += c.shadow; counters->samples += c.samples; }
     return RT_OK;
 }
+
+uint32_t rt_sample_segment(void) { return RT_SAMPLE_SEGMENT; }
 
 int rt_strip_rows(uint32_t height, uint32_t strip_height, uint32_t strip_first, uint32_t strip_period) {
     if (strip_height == 0 || strip_period == 0 || strip_first >= strip_period) return RT_E_INVALID;

@@ -12,7 +12,7 @@ frame needs exactly ONE exchange step:
     Bit-identical to a single-GPU render by construction (counter-based RNG,
     fixed per-pixel sample order).
   * spp mode   : every rank renders the full frame for a contiguous range of
-    sample indices (multiples of the 32-sample segment) into a float3 accumulator
+    sample indices (multiples of the sample segment (rt_sample_segment)) into a float3 accumulator
     of per-sample-clamped sums (implementation.rs:635,656: the clamp is per sample,
     so sums add); rank 0 gathers the accumulators and adds them IN RANK ORDER
     (deterministic), then divides and converts once.  A plain all-reduce would do
@@ -24,9 +24,7 @@ Nothing here touches pixels; it only moves them.  Works on any backend
 import torch
 import torch.distributed as dist
 
-from .scene import create_render_chunks
-
-SAMPLE_SEGMENT = 32   # RT_SAMPLE_SEGMENT of csrc/render.hip
+from .scene import create_render_chunks, sample_segment
 
 
 def _gather(tensor, gather_list, dst, rank, world):
@@ -55,10 +53,11 @@ def chunks_of_rank(chunks, rank, world):
 
 def sample_range_of_rank(samples_per_pixel, rank, world):
     """Contiguous [first, first+count) of sample indices for `rank`; boundaries fall on
-    multiples of the 32-sample segment so that every segment sum is formed on one rank."""
-    segs = (samples_per_pixel + SAMPLE_SEGMENT - 1) // SAMPLE_SEGMENT
-    lo = (segs * rank) // world * SAMPLE_SEGMENT
-    hi = min((segs * (rank + 1)) // world * SAMPLE_SEGMENT, samples_per_pixel)
+    multiples of the sample segment (rt_sample_segment) so that every segment sum is formed on one rank."""
+    seg = sample_segment()
+    segs = (samples_per_pixel + seg - 1) // seg
+    lo = (segs * rank) // world * seg
+    hi = min((segs * (rank + 1)) // world * seg, samples_per_pixel)
     return lo, max(0, hi - lo)
 
 

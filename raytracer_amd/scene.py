@@ -322,6 +322,11 @@ class Scene:
         return t, n, e, tri
 
 
+def sample_segment():
+    """Segment length of the fixed per-pixel sample summation order (rt_sample_segment)."""
+    return int(_ffi.load_hip().rt_sample_segment())
+
+
 def strip_rows(height, strip_height, strip_first, strip_period):
     n = _ffi.load_hip().rt_strip_rows(height, strip_height, strip_first, strip_period)
     if n < 0:

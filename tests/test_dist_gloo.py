@@ -27,7 +27,7 @@ def _worker(rank, world, port, mode, result_path):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from raytracer_amd import CameraConfiguration, RenderChunk, RenderSettings, SceneBuilder
+        from raytracer_amd import CameraConfiguration, RenderChunk, RenderSettings, SceneBuilder, sample_segment
         from raytracer_amd.dist import StripCompositor, reduce_accumulators, sample_range_of_rank, strip_chunks
         from tests.oracle import ORC_RNG_COUNTER, OracleScene
         b = SceneBuilder.sample("Random Spheres", CameraConfiguration(W, H))
@@ -47,7 +47,7 @@ def _worker(rank, world, port, mode, result_path):
                 np.save(result_path, np.array([float(np.array_equal(frame.numpy(), full))]))
         else:
             first, count = sample_range_of_rank(SPP, rank, world)
-            assert first % 32 == 0
+            assert first % sample_segment() == 0
             acc = torch.from_numpy(o.accumulate_chunk(st, whole, SEED, first, count))
             total = reduce_accumulators(acc, rank, world)
             if rank == 0:
@@ -72,6 +72,7 @@ def test_two_ranks_gloo(mode, tmp_path):
 
 def test_partition_helpers():
     sys.path.insert(0, ROOT)
+    from raytracer_amd import sample_segment
     from raytracer_amd.dist import chunks_of_rank, sample_range_of_rank, strip_chunks
     for world in (1, 2, 4, 8):
         chunks = strip_chunks(1920, 1080, world)
@@ -84,7 +85,7 @@ def test_partition_helpers():
             pos = 0
             for f, c in ranges:
                 if c:
-                    assert f == pos and f % 32 == 0
+                    assert f == pos and f % sample_segment() == 0
                     pos += c
     assert len(strip_chunks(64, 5, 8)) == 5        # never more strips than rows
 

@@ -15,7 +15,8 @@ Tolerances
 import numpy as np
 import pytest
 
-from raytracer_amd import CameraConfiguration, RenderChunk, RenderSettings, Scene, SceneBuilder, create_render_chunks
+from raytracer_amd import (CameraConfiguration, RenderChunk, RenderSettings, Scene, SceneBuilder, create_render_chunks,
+                           sample_segment)
 from tests.oracle import ORC_RNG_COUNTER, OracleScene
 
 pytestmark = pytest.mark.gpu
@@ -82,7 +83,7 @@ def test_image_matches_oracle(name, w, h, spp, depth):
     st = RenderSettings(w, h, depth, spp)
     ch = RenderChunk(0, 0, w, h)
     rgb, rgba, cn = scene.render_chunk(st, ch, seed=12345)
-    ref, ref_rgba, rcn = oracle.render_chunk(st, ch, ORC_RNG_COUNTER, 12345, sum_segment=32)
+    ref, ref_rgba, rcn = oracle.render_chunk(st, ch, ORC_RNG_COUNTER, 12345, sum_segment=sample_segment())
     out, mean, mx = check_image(rgb, ref)
     print(f"{name}: outliers {out:.5f} mean {mean:.2e} max {mx:.2e}; rays gpu {cn.primary}/{cn.secondary}/{cn.shadow} "
           f"oracle {rcn.rays.primary}/{rcn.rays.secondary}/{rcn.rays.shadow}")
@@ -160,9 +161,10 @@ def test_spp_split_accumulators_sum_to_the_full_render():
     resolve_device(0, acc.data_ptr(), w * h, spp, rgb.data_ptr(), None, stream)
     torch.cuda.synchronize()
     assert np.array_equal(rgb.cpu().numpy(), whole)      # sequential segment order preserved
-    part = oracle.accumulate_chunk(st, ch, 3, 32, 32)
+    seg = sample_segment()
+    part = oracle.accumulate_chunk(st, ch, 3, seg, seg)
     acc.zero_()
-    scene.accumulate_chunk_device(st, ch, 3, 32, 32, acc.data_ptr(), None, stream)
+    scene.accumulate_chunk_device(st, ch, 3, seg, seg, acc.data_ptr(), None, stream)
     torch.cuda.synchronize()
     d = np.abs(acc.cpu().numpy() - part)
     assert (d.max(axis=2) > 1e-3).mean() < 2e-3 and d.mean() < 1e-4
