@@ -1,4 +1,4 @@
-import sys, time; sys.path.insert(0,'.')
+import sys, time; sys.path.insert(0,'.'); sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import torch
 from raytracer_amd import *
 W,H,spp=1920,1080,256
