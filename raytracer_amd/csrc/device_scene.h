@@ -20,8 +20,11 @@ struct alignas(16) Word4 {
 // The reference's tree (bvh.rs:18-48: one box per node, enum Branch/Leaf) is
 // re-laid so that one visit fetches one line and tests two boxes.  Box values
 // are the reference's, unchanged.
-//   w0 = (lmin.x lmin.y lmin.z lmax.x)   w1 = (lmax.y lmax.z rmin.x rmin.y)
-//   w2 = (rmin.z rmax.x rmax.y rmax.z)   w3.u = (left ref, right ref, -, -)
+// Same-axis planes of the LEFT and RIGHT box sit in adjacent dwords, so that after
+// three dwordx4 loads they are aligned register pairs for packed f32 math
+// (v_pk_add_f32 / v_pk_mul_f32 test both boxes at once):
+//   w0 = (lmin.x rmin.x lmin.y rmin.y)   w1 = (lmin.z rmin.z lmax.x rmax.x)
+//   w2 = (lmax.y rmax.y lmax.z rmax.z)   w3.u = (left ref, right ref, -, -)
 // child ref: bit31 = 0 -> inner node index (relative to the BVH's node base)
 //            bit31 = 1 -> leaf: bits 28..30 = count-1 (1..8), bits 0..27 = first
 //                        object position (relative to the BVH's object base)
@@ -80,6 +83,7 @@ struct DevSceneView {
     float tlas_min[3], tlas_max[3];
     uint32_t tlas_root_ref;
     uint32_t stack_entries;       // per-lane traversal stack depth the trees need
+    uint32_t shadow_any_hit;      // no dielectric material in the scene: any occluder ends a shadow ray
     const DevNode* nodes;         // TLAS nodes first, then every BLAS
     const DevEntity* entities;    // TLAS leaf order
     const Word4* xforms;

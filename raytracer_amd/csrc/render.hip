@@ -164,6 +164,25 @@ __device__ __forceinline__ bool slab(float lox, float loy, float loz, float hix,
     return !(tf < tn);
 }
 
+// The same test for the two boxes of one node at once, on register pairs
+// (left, right): every operation of slab() is done component-wise on the pair, so
+// each half is bit-identical to slab() on that box.
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void slab2(const Word4& a, const Word4& b, const Word4& c, F3 o, F3 inv, float t_min, float t_max,
+                                      bool& hl, bool& hr, float& el, float& er) {
+    const f2 lox = {a.f[0], a.f[1]}, loy = {a.f[2], a.f[3]}, loz = {b.f[0], b.f[1]};
+    const f2 hix = {b.f[2], b.f[3]}, hiy = {c.f[0], c.f[1]}, hiz = {c.f[2], c.f[3]};
+    const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
+    const f2 ax = ((nx ? hix : lox) - o.x) * inv.x, bx = ((nx ? lox : hix) - o.x) * inv.x;
+    const f2 ay = ((ny ? hiy : loy) - o.y) * inv.y, by = ((ny ? loy : hiy) - o.y) * inv.y;
+    const f2 az = ((nz ? hiz : loz) - o.z) * inv.z, bz = ((nz ? loz : hiz) - o.z) * inv.z;
+    el = fmaxf(fmaxf(fmaxf(ax.x, ay.x), az.x), t_min);
+    er = fmaxf(fmaxf(fmaxf(ax.y, ay.y), az.y), t_min);
+    const float fl = fminf(fminf(fminf(bx.x, by.x), bz.x), t_max);
+    const float fr = fminf(fminf(fminf(bx.y, by.y), bz.y), t_max);
+    hl = !(fl < el); hr = !(fr < er);
+}
+
 // Entity::hit's world -> entity ray transform, implementation.rs:288-294
 __device__ __forceinline__ void ray_to_entity(const DevSceneView& S, const Word4& e0, const Word4& e1, F3& o, F3& d) {
     const uint32_t packed = e1.u[0];
@@ -214,9 +233,8 @@ __device__ __forceinline__ void trace(const DevSceneView& S, const F3 wo, const 
         while (cur < RT_REF_LEAF_BIT) {
             const Word4* n = nodes[cur].w;
             const Word4 a = ldw(n), b = ldw(n + 1), c = ldw(n + 2), r = ldw(n + 3);
-            float el, er;
-            const bool hl = slab(a.f[0], a.f[1], a.f[2], a.f[3], b.f[0], b.f[1], o, inv, t_min, best_t, el);
-            const bool hr = slab(b.f[2], b.f[3], c.f[0], c.f[1], c.f[2], c.f[3], o, inv, t_min, best_t, er);
+            float el, er; bool hl, hr;
+            slab2(a, b, c, o, inv, t_min, best_t, hl, hr, el, er);
             if (hl && hr) {
                 const bool left_first = el <= er;
                 const uint32_t far_ref = left_first ? r.u[1] : r.u[0];
@@ -787,9 +805,8 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                 while (cur < RT_REF_LEAF_BIT) {
                     const Word4* n = nodes[cur].w;
                     const Word4 na = ldw(n), nb = ldw(n + 1), nc = ldw(n + 2), nr = ldw(n + 3);
-                    float el, er;
-                    const bool hl = slab(na.f[0], na.f[1], na.f[2], na.f[3], nb.f[0], nb.f[1], o, inv, t_min, best_t, el);
-                    const bool hr = slab(nb.f[2], nb.f[3], nc.f[0], nc.f[1], nc.f[2], nc.f[3], o, inv, t_min, best_t, er);
+                    float el, er; bool hl, hr;
+                    slab2(na, nb, nc, o, inv, t_min, best_t, hl, hr, el, er);
                     if (hl && hr) {
                         const bool left_first = el <= er;
                         const uint32_t far_ref = left_first ? nr.u[1] : nr.u[0];
@@ -897,6 +914,8 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                         if (!entered) cur = pop();
                     }
                 }
+                // a shadow ray of a scene without dielectrics is decided by ANY occluder
+                if (S.shadow_any_hit && state == SHADOW && best.ent != RT_NONE) cur = RT_NONE;
                 if (cur == RT_NONE) tracing = false;      // closest hit (or miss) is in `best`
             }
             // leave the burst when enough lanes can take a new ray, or nobody is tracing

@@ -131,9 +131,9 @@ struct Emitter {
         return RT_REF_LEAF_BIT | ((count - 1) << RT_REF_COUNT_SHIFT) | (first & RT_REF_FIRST_MASK);
     }
     static void put_boxes(DevNode& d, const Box& l, const Box& r) {
-        d.w[0].f[0] = l.lo.x; d.w[0].f[1] = l.lo.y; d.w[0].f[2] = l.lo.z; d.w[0].f[3] = l.hi.x;
-        d.w[1].f[0] = l.hi.y; d.w[1].f[1] = l.hi.z; d.w[1].f[2] = r.lo.x; d.w[1].f[3] = r.lo.y;
-        d.w[2].f[0] = r.lo.z; d.w[2].f[1] = r.hi.x; d.w[2].f[2] = r.hi.y; d.w[2].f[3] = r.hi.z;
+        d.w[0].f[0] = l.lo.x; d.w[0].f[1] = r.lo.x; d.w[0].f[2] = l.lo.y; d.w[0].f[3] = r.lo.y;
+        d.w[1].f[0] = l.lo.z; d.w[1].f[1] = r.lo.z; d.w[1].f[2] = l.hi.x; d.w[1].f[3] = r.hi.x;
+        d.w[2].f[0] = l.hi.y; d.w[2].f[1] = r.hi.y; d.w[2].f[2] = l.hi.z; d.w[2].f[3] = r.hi.z;
     }
     // A leaf of more than RT_LEAF_MAX objects (only when a split left one side
     // empty, bvh.rs:169) becomes a small subtree whose boxes all equal the leaf's
@@ -392,6 +392,10 @@ int build_flat_scene(const RtSceneDesc* d, FlatScene& out, std::string& err) {
         p.w[1].f[0] = s.u_basis.x; p.w[1].f[1] = s.u_basis.y; p.w[1].f[2] = s.u_basis.z; p.w[1].u[3] = s.has_radius ? 1u : 0u;
         p.w[2].f[0] = s.v_basis.x; p.w[2].f[1] = s.v_basis.y; p.w[2].f[2] = s.v_basis.z; p.w[2].f[3] = 0.0f;
     }
+    // cast_light_ray_to_lamp (implementation.rs:535-552) only looks past an occluder whose
+    // scatter yields a refraction, i.e. a MatDielectric; without any, the first hit found decides.
+    v.shadow_any_hit = 1;
+    for (uint64_t i = 0; i < n_mat; i++) if (d->materials[i].kind == RT_MAT_DIELECTRIC) v.shadow_any_hit = 0;
     out.materials.resize(n_mat ? n_mat : 1);
     for (uint64_t i = 0; i < n_mat; i++) {
         const RtMaterial& s = d->materials[i]; DevMaterial& m = out.materials[i];
