@@ -20,9 +20,9 @@ struct alignas(16) Word4 {
 // The reference's tree (bvh.rs:18-48: one box per node, enum Branch/Leaf) is
 // re-laid so that one visit fetches one line and tests two boxes.  Box values
 // are the reference's, unchanged.
-// Same-axis planes of the LEFT and RIGHT box sit in adjacent dwords, so that after
-// three dwordx4 loads they are aligned register pairs for packed f32 math
-// (v_pk_add_f32 / v_pk_mul_f32 test both boxes at once):
+// Same-axis planes of the LEFT and RIGHT box sit in adjacent dwords (three dwordx4
+// loads bring both boxes; the pairing is what a packed-math test would want, which
+// measured slower than scalar on gfx950 - see slab2 in render.hip):
 //   w0 = (lmin.x rmin.x lmin.y rmin.y)   w1 = (lmin.z rmin.z lmax.x rmax.x)
 //   w2 = (lmax.y rmax.y lmax.z rmax.z)   w3.u = (left ref, right ref, -, -)
 // child ref: bit31 = 0 -> inner node index (relative to the BVH's node base)

@@ -164,23 +164,14 @@ __device__ __forceinline__ bool slab(float lox, float loy, float loz, float hix,
     return !(tf < tn);
 }
 
-// The same test for the two boxes of one node at once, on register pairs
-// (left, right): every operation of slab() is done component-wise on the pair, so
-// each half is bit-identical to slab() on that box.
-typedef float f2 __attribute__((ext_vector_type(2)));
+// The two boxes of one node record (layout: device_scene.h).  Packed f32 math
+// (v_pk_add_f32 / v_pk_mul_f32 on the left/right pair) was measured 1-2 % SLOWER than
+// two plain tests, and compiler SLP packing of the F3 arithmetic 9 % slower, on
+// gfx950: the build uses -fno-slp-vectorize and this stays scalar.
 __device__ __forceinline__ void slab2(const Word4& a, const Word4& b, const Word4& c, F3 o, F3 inv, float t_min, float t_max,
                                       bool& hl, bool& hr, float& el, float& er) {
-    const f2 lox = {a.f[0], a.f[1]}, loy = {a.f[2], a.f[3]}, loz = {b.f[0], b.f[1]};
-    const f2 hix = {b.f[2], b.f[3]}, hiy = {c.f[0], c.f[1]}, hiz = {c.f[2], c.f[3]};
-    const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
-    const f2 ax = ((nx ? hix : lox) - o.x) * inv.x, bx = ((nx ? lox : hix) - o.x) * inv.x;
-    const f2 ay = ((ny ? hiy : loy) - o.y) * inv.y, by = ((ny ? loy : hiy) - o.y) * inv.y;
-    const f2 az = ((nz ? hiz : loz) - o.z) * inv.z, bz = ((nz ? loz : hiz) - o.z) * inv.z;
-    el = fmaxf(fmaxf(fmaxf(ax.x, ay.x), az.x), t_min);
-    er = fmaxf(fmaxf(fmaxf(ax.y, ay.y), az.y), t_min);
-    const float fl = fminf(fminf(fminf(bx.x, by.x), bz.x), t_max);
-    const float fr = fminf(fminf(fminf(bx.y, by.y), bz.y), t_max);
-    hl = !(fl < el); hr = !(fr < er);
+    hl = slab(a.f[0], a.f[2], b.f[0], b.f[2], c.f[0], c.f[2], o, inv, t_min, t_max, el);
+    hr = slab(a.f[1], a.f[3], b.f[1], b.f[3], c.f[1], c.f[3], o, inv, t_min, t_max, er);
 }
 
 // Entity::hit's world -> entity ray transform, implementation.rs:288-294
@@ -528,6 +519,9 @@ struct RenderParams {
     unsigned long long* counters;                   // RtRayCounters on the device (nullable)
     uint32_t refill_lanes;                          // idle lanes that end a traversal burst
     uint32_t* block_counter;                        // next unclaimed block of 64 work items (zeroed per launch)
+#ifdef RT_PHASE_STATS
+    unsigned long long* phase_stats;                // diagnostics build only: [phase][lane-iterations, wave-iterations]
+#endif
     uint32_t strip_h, strip_period_rows, strip_first_row;   // strip_h != 0: local row y -> image row (interleaved strips)
 };
 
@@ -550,6 +544,15 @@ __device__ __forceinline__ void gen_camera_ray(const DevSceneView& S, float u, f
 #define RT_REFILL_LANES 64
 #endif
 
+// Diagnostics build (make stats): per phase, how many lanes and how many wave
+// passes went through it; lane utilisation of a phase = lanes / (64 * passes).
+#ifdef RT_PHASE_STATS
+enum { PH_NODE = 0, PH_TRI, PH_ENTITY, PH_SHADE, PH_SHADE_PATH_HIT, PH_SHADE_SHADOW_HIT, PH_STAGE_A, PH_STAGE_C, PH_TRACE_INIT, PH_BURST, PH_LEAF_TRI, PH_LEAF_TLAS, PH_OUTER, PH_POP_INST, PH_COUNT };
+#define PH(i) do { const unsigned long long m_ = __ballot(1); ph_lanes[i]++; ph_waves[i] += (lane == (uint32_t)(__ffsll((long long)m_) - 1)); } while (0)
+#else
+#define PH(i) do { } while (0)
+#endif
+
 __global__ void __launch_bounds__(RT_BLOCK, RT_WAVES_PER_SIMD)
 render_kernel(const DevSceneView S, const RenderParams P) {
     extern __shared__ uint32_t lds_stack[];
@@ -565,6 +568,9 @@ render_kernel(const DevSceneView S, const RenderParams P) {
     const uint32_t lane = threadIdx.x & 63u;
 
     uint32_t n_primary = 0, n_secondary = 0, n_shadow = 0, n_samples = 0;
+#ifdef RT_PHASE_STATS
+    uint32_t ph_lanes[PH_COUNT] = {}, ph_waves[PH_COUNT] = {};
+#endif
 
     // Lane state between two rays.  PATH / SHADOW: a ray of that kind is in flight
     // (or, with `tracing` false, has just finished and waits for its shading).
@@ -592,6 +598,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
     const DevNode* nodes = S.nodes;
 
     for (;;) {
+        PH(PH_OUTER);
         // ================= next block of work items: all lanes of the wave together ======
         if (__ballot(state != NEED_BLOCK && state != FINISHED) == 0ull) {
             if (state == NEED_BLOCK) {
@@ -623,6 +630,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
         }
         if (!tracing && state != NEED_BLOCK && state != FINISHED) {
             // ================= shading of the ray that just finished =====================
+            PH(PH_SHADE);
             if (state == SHADOW) {
                 // cast_light_ray_to_lamp, implementation.rs:535-552
                 n_shadow++;
@@ -634,6 +642,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                     // Only a dielectric can let light through (scatter yields a refraction only
                     // there, materials.rs:45-53,90-112,168-190): look at the material first,
                     // rebuild the hit record only if needed.
+                    PH(PH_SHADE_SHADOW_HIT);
                     const uint32_t mat_id = ldw(S.entities[best.ent].w + 1).u[3];
                     const Word4* mw = S.materials[mat_id].w;
                     const Word4 m0 = ldw(mw);
@@ -657,6 +666,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                 if (rnode == 1u) n_primary++; else n_secondary++;
                 if (best.ent == RT_NONE) { sample_col = sample_col + (rw * color_sky(S, rd)); state = NEED_PATH; }
                 else {
+                    PH(PH_SHADE_PATH_HIT);
                     HitRec hr; resolve_hit(S, ro, rd, best, hr);
                     const Word4* mw = S.materials[hr.mat_id].w;
                     const Word4 m0 = ldw(mw);
@@ -718,6 +728,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
             // ================= next ray of this lane =======================================
             // stage A: next light of the current hit (implementation.rs:612-621)
             if (state == NEED_LIGHT) {
+                PH(PH_STAGE_A);
                 while (light_k < S.light_count) {
                     LightRec lr;
                     if (light_record(S, light_k, hp, lr)) {
@@ -749,6 +760,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
             // stage C: next sample / next work item
             while (state == NEED_SAMPLE) {
                 if (s < s_end) {
+                    PH(PH_STAGE_C);
                     float lx = 0.0f, ly = 0.0f;
                     if (P.spp > 1) {                                                  // :648-653
                         float r0, r1; rng_pair(P.seed, px, py, s, 0u, PURPOSE_LENS, r0, r1);
@@ -771,6 +783,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
             }
             // ================= start the traversal of the new ray ==========================
             if (state == PATH || state == SHADOW) {
+                PH(PH_TRACE_INIT);
                 const bool shadow = state == SHADOW;
                 o = shadow ? hp : ro;
                 d = shadow ? -ldir : rd;
@@ -790,6 +803,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
         // next deferred subtree; leaving a BLAS restores the world-space ray
         auto pop = [&]() -> uint32_t {
             if (sp == inst_sp) {
+                PH(PH_POP_INST);
                 inst_sp = RT_NONE; nodes = S.nodes;
                 const bool shadow = state == SHADOW;
                 o = shadow ? hp : ro; d = shadow ? -ldir : rd;
@@ -800,9 +814,11 @@ render_kernel(const DevSceneView S, const RenderParams P) {
         };
         for (;;) {
             if (tracing) {
+                PH(PH_BURST);
                 // ---- phase 1: walk inner nodes until this lane holds a leaf (RT_NONE has
                 // the leaf bit set and ends the walk too).  One 64-byte record = two boxes.
                 while (cur < RT_REF_LEAF_BIT) {
+                    PH(PH_NODE);
                     const Word4* n = nodes[cur].w;
                     const Word4 na = ldw(n), nb = ldw(n + 1), nc = ldw(n + 2), nr = ldw(n + 3);
                     float el, er; bool hl, hr;
@@ -820,8 +836,10 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                     const uint32_t first = cur & RT_REF_FIRST_MASK;
                     const uint32_t count = ((cur >> RT_REF_COUNT_SHIFT) & 7u) + 1u;
                     if (inst_sp != RT_NONE) {
+                        PH(PH_LEAF_TRI);
                         // try_hit_tri, mesh.rs:18-76 (normal precomputed with the same ops)
                         for (uint32_t k = 0; k < count; k++) {
+                            PH(PH_TRI);
                             const uint32_t ti = tri_base + first + k;
                             const Word4* tw = S.tri_hot[ti].w;
                             const Word4 ta = ldw(tw), tb = ldw(tw + 1), tc = ldw(tw + 2);
@@ -851,10 +869,12 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                     } else {
                         // TLAS leaf: its entities in order; a mesh entity defers the rest of the
                         // leaf and turns the walk into its BLAS.
+                        PH(PH_LEAF_TLAS);
                         const bool shadow = state == SHADOW;
                         const F3 wo = shadow ? hp : ro, wd = shadow ? -ldir : rd;
                         bool entered = false;
                         for (uint32_t k = 0; k < count && !entered; k++) {
+                            PH(PH_ENTITY);
                             const uint32_t ei = first + k;
                             const Word4* ew = S.entities[ei].w;
                             const Word4 e0 = ldw(ew), e1 = ldw(ew + 1);
@@ -925,6 +945,13 @@ render_kernel(const DevSceneView S, const RenderParams P) {
         }
     }
 
+#ifdef RT_PHASE_STATS
+    for (int k = 0; k < PH_COUNT; k++) {
+        uint32_t a = ph_lanes[k], b = ph_waves[k];
+        for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off, 64); b += __shfl_down(b, off, 64); }
+        if (lane == 0) { atomicAdd(P.phase_stats + 2 * k, (unsigned long long)a); atomicAdd(P.phase_stats + 2 * k + 1, (unsigned long long)b); }
+    }
+#endif
     // ---- ray counters: wave reduce, one atomic per wave and class ------------------
     if (P.counters) {
         uint32_t v[4] = {n_primary, n_secondary, n_shadow, n_samples};
@@ -1104,8 +1131,24 @@ int enqueue_accumulate(RtScene* scene, const RtSettings* st, const RtRenderChunk
         HIP_TRY(hipMemsetAsync(P.block_counter, 0, sizeof(uint32_t), stream));
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
         if (scene->profiling) { HIP_TRY(hipEventCreate(&ev0)); HIP_TRY(hipEventCreate(&ev1)); HIP_TRY(hipEventRecord(ev0, stream)); }
+#ifdef RT_PHASE_STATS
+        static unsigned long long* phase_dev = nullptr;
+        if (!phase_dev) HIP_TRY(hipMalloc((void**)&phase_dev, PH_COUNT * 16));
+        HIP_TRY(hipMemsetAsync(phase_dev, 0, PH_COUNT * 16, stream));
+        P.phase_stats = phase_dev;
+#endif
         hipLaunchKernelGGL(render_kernel, dim3((uint32_t)blocks), dim3(RT_BLOCK), scene->lds_bytes, stream, scene->view, P);
         HIP_TRY(hipGetLastError());
+#ifdef RT_PHASE_STATS
+        {
+            unsigned long long h[PH_COUNT * 2];
+            HIP_TRY(hipMemcpyAsync(h, phase_dev, sizeof(h), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+            static const char* names[PH_COUNT] = {"node", "tri", "entity", "shade", "shade_path_hit", "shade_shadow_hit", "stage_a", "stage_c", "trace_init", "burst", "leaf_tri", "leaf_tlas", "outer", "pop_inst"};
+            for (int k = 0; k < PH_COUNT; k++)
+                fprintf(stderr, "phase %-18s lanes %14llu passes %12llu util %.3f\n", names[k], h[2 * k], h[2 * k + 1], h[2 * k + 1] ? (double)h[2 * k] / (64.0 * (double)h[2 * k + 1]) : 0.0);
+        }
+#endif
         if (scene->profiling) { HIP_TRY(hipEventRecord(ev1, stream)); scene->profile_events.emplace_back(ev0, ev1); }
         hipLaunchKernelGGL(fold_kernel, dim3((npix + 255) / 256), dim3(256), 0, stream, (const float*)scene->partial.p, bn, npix, acc, acc_pitch,
                            ch->width, acc_x, acc_y, (init_zero && b0 == 0) ? 1 : 0);
