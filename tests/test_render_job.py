@@ -1,0 +1,77 @@
+"""The C++ host harness (raytracer_amd/rt_render = render_job.cpp over the C ABI):
+the reference's RenderJob / worker-thread protocol (src/render.rs:18-224).
+
+CPU part: the job machinery with a synthetic per-chunk pattern (every chunk rendered
+exactly once, blitted at its place, by any number of threads).  GPU part: the frame it
+assembles from rt_render_chunk calls of several threads equals the one-call frame.
+"""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "raytracer_amd", "rt_render")
+
+
+def run(args, tmp_path, expect_rc=0):
+    out = str(tmp_path / "frame.ppm")
+    p = subprocess.run([EXE] + args + ["--out", out], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert p.returncode == expect_rc, p.stderr
+    if expect_rc != 0:
+        return None, None, p.stderr
+    info = json.loads(p.stdout.strip().splitlines()[-1])
+    with open(out, "rb") as f:
+        assert f.readline() == b"P6\n"
+        w, h = map(int, f.readline().split())
+        assert f.readline() == b"255\n"
+        img = np.frombuffer(f.read(), dtype=np.uint8).reshape(h, w, 3)
+    return info, img, p.stderr
+
+
+@pytest.mark.parametrize("w,h,cx,cy,threads", [(130, 70, 3, 4, 3), (64, 64, 1, 1, 1), (97, 41, 8, 8, 5), (33, 17, 2, 16, 16)])
+def test_job_machinery_self_test(tmp_path, w, h, cx, cy, threads):
+    info, img, _ = run(["--self-test", "--width", str(w), "--height", str(h), "--chunks", f"{cx}x{cy}", "--threads", str(threads)], tmp_path)
+    ax, ay = np.meshgrid(np.arange(w, dtype=np.uint32), np.arange(h, dtype=np.uint32))
+    expect = np.stack([(ax * 7) & 255, (ay * 13) & 255, ((ax ^ ay) * 3) & 255], axis=2).astype(np.uint8)
+    assert np.array_equal(img, expect)
+    assert info["chunks"] == cx * cy and sum(info["chunks_per_thread"]) == cx * cy
+    assert info["rays"]["samples"] == w * h          # every pixel exactly once
+    assert len(info["chunks_per_thread"]) == threads
+
+
+def test_lists_the_scene_factories():
+    p = subprocess.run([EXE, "--list"], cwd=ROOT, capture_output=True, text=True, timeout=60)
+    names = p.stdout.strip().splitlines()
+    assert "Random Spheres" in names and "Mesh" in names and len(names) >= 12
+
+
+def test_fails_loudly_without_a_device(tmp_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    _, _, err = run(["--width", "32", "--height", "18"], tmp_path, expect_rc=1)
+    assert "no HIP device" in err
+
+
+def test_unknown_scene_is_an_error(tmp_path):
+    _, _, err = run(["--scene", "No Such Scene"], tmp_path, expect_rc=1)
+    assert "rt_render:" in err
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,params", [("Random Spheres", None), ("Mesh", None)])
+def test_threads_and_chunks_assemble_the_one_call_frame(tmp_path, name, params):
+    from raytracer_amd import CameraConfiguration, RenderChunk, RenderSettings, Scene, SceneBuilder
+    w, h, spp, depth = 200, 112, 4, 8
+    info, img, _ = run(["--scene", name, "--width", str(w), "--height", str(h), "--spp", str(spp), "--depth", str(depth),
+                        "--chunks", "4x4", "--threads", "3", "--seed", "12345"], tmp_path)
+    b = SceneBuilder.sample(name, CameraConfiguration(w, h, lens_radius=0.1))
+    scene = Scene(b, 0)
+    _, rgba, cn = scene.render_chunk(RenderSettings(w, h, depth, spp), RenderChunk(0, 0, w, h), seed=12345)
+    assert np.array_equal(img, rgba[:, :, :3])
+    r = info["rays"]
+    assert (r["primary"], r["secondary"], r["shadow"], r["samples"]) == (cn.primary, cn.secondary, cn.shadow, cn.samples)
+    assert sum(info["chunks_per_thread"]) == 16
