@@ -38,6 +38,7 @@ typedef struct RtCameraConfig {
 typedef struct RtSceneBuilder RtSceneBuilder;
 
 const char* rt_samples_last_error(void);
+const char* rt_samples_last_warning(void);
 
 /* CameraConfiguration::make_camera(look_to, default_look_from). */
 int rt_make_camera(const RtCameraConfig* config, const float* look_to3,
@@ -54,12 +55,22 @@ int rt_builder_add_material(RtSceneBuilder* b, const RtMaterial* m);
 int rt_builder_add_texture(RtSceneBuilder* b, const RtTexture* t);
 /* ColorMap: copies width*height texels (row 0 = top), returns TexId */
 int rt_builder_add_color_map(RtSceneBuilder* b, uint32_t width, uint32_t height, const float* rgb);
+/* load_color_map(path) (raytracer-obj/src/builder.rs:159-172, color_map.rs:16-33):
+ * decodes a PNG or BMP file into a ColorMap texture (channel / 255.0, row 0 = top,
+ * alpha dropped) and returns its TexId. */
+int rt_builder_load_color_map(RtSceneBuilder* b, const char* path);
+/* The decoder on its own: RGBA8, row 0 = top.  With rgba_out NULL only the size is
+ * returned; otherwise capacity must be >= width*height*4. */
+int rt_image_decode(const char* path, uint32_t* width, uint32_t* height,
+                    uint8_t* rgba_out, uint64_t capacity);
 int rt_builder_add_light(RtSceneBuilder* b, const RtLight* l);
 /* Mesh{tris}: copies the triangles, returns the mesh index (shared geometry) */
 int rt_builder_add_mesh(RtSceneBuilder* b, const RtMeshTri* tris, uint64_t count);
 /* load_obj_builder(path).build_mesh(): parses OBJ (+ MTL when present) and adds
- * the mesh and, as one MESH_SET texture, its MeshTextureSet.  Colour maps are
- * NOT decoded here (map_Kd is treated as missing: diffuse colour only).
+ * the mesh and, as one MESH_SET texture, its MeshTextureSet.  Every map_Kd file of
+ * the MTL is decoded into a ColorMap (builder.rs:121-131); a missing or undecodable
+ * file fails the load as in the reference, except a git-lfs pointer file, which is
+ * skipped (diffuse colour only) and reported by rt_samples_last_warning().
  * Returns mesh index; *texture_set_out (nullable) receives the TexId. */
 int rt_builder_load_obj(RtSceneBuilder* b, const char* path, int* texture_set_out);
 /* Entity::new(hitable).translate(..)*.rotate(..)*.id(..); `hitable_kind`

@@ -183,6 +183,9 @@ SAMPLES_PROTOTYPES = {
     "rt_builder_add_material": (C.c_int, [C.c_void_p, _P(RtMaterial)]),
     "rt_builder_add_texture": (C.c_int, [C.c_void_p, _P(RtTexture)]),
     "rt_builder_add_color_map": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
+    "rt_builder_load_color_map": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "rt_image_decode": (C.c_int, [C.c_char_p, _P(C.c_uint32), _P(C.c_uint32), C.c_void_p, C.c_uint64]),
+    "rt_samples_last_warning": (C.c_char_p, []),
     "rt_builder_add_light": (C.c_int, [C.c_void_p, _P(RtLight)]),
     "rt_builder_add_mesh": (C.c_int, [C.c_void_p, _P(RtMeshTri), C.c_uint64]),
     "rt_builder_load_obj": (C.c_int, [C.c_void_p, C.c_char_p, _P(C.c_int)]),

@@ -11,6 +11,7 @@
 // -ffp-contract=off) because sphere positions, camera bases and rotations feed
 // straight into the parity-checked path.
 #include "../../include/rt_samples.h"
+#include "image_decode.h"
 
 #include <cmath>
 #include <cstdio>
@@ -25,6 +26,7 @@
 namespace {
 
 thread_local std::string g_error;
+thread_local std::string g_warning;
 
 struct Vec { float x, y, z; };
 inline Vec mk(float x, float y, float z) { return Vec{x, y, z}; }
@@ -117,6 +119,14 @@ struct RtSceneBuilder {
     // --- Scene::add_* ---
     uint32_t add_material(const RtMaterial& m) { materials.push_back(m); return (uint32_t)materials.size() - 1; }
     uint32_t add_texture(const RtTexture& t) { textures.push_back(t); return (uint32_t)textures.size() - 1; }
+    // rgba_to_v3, color_map.rs:9-14: channel as f32 / 255.0, alpha dropped
+    uint32_t add_color_map_rgba8(uint32_t w, uint32_t h, const uint8_t* rgba) {
+        RtTexture t{}; t.kind = RT_TEX_COLOR_MAP; t.width = w; t.height = h; t.texel_first = texels.size(); t.child0 = t.child1 = -1;
+        texels.reserve(texels.size() + (size_t)w * h);
+        for (uint64_t i = 0; i < (uint64_t)w * h; i++)
+            texels.push_back(RtV3{(float)rgba[4 * i] / 255.0f, (float)rgba[4 * i + 1] / 255.0f, (float)rgba[4 * i + 2] / 255.0f});
+        return add_texture(t);
+    }
     void add_light(const RtLight& l) { lights.push_back(l); }
     uint32_t add_mesh(std::vector<RtMeshTri> tris) { mesh_tris.push_back(std::move(tris)); return (uint32_t)mesh_tris.size() - 1; }
 
@@ -402,12 +412,32 @@ int load_obj_mesh(RtSceneBuilder& b, const std::string& path, int* texture_set_o
         tris.push_back(t);
     }
     if (tris.empty()) { g_error = "[ObjMeshBuilder::inner_build_mesh] expected at least one face"; return RT_E_IO; }
+    // colour maps of EVERY material of the MTL, used or not; a file that is missing or
+    // does not decode fails the whole load (builder.rs:121-131).  One exception, not in
+    // the reference: a git-lfs pointer (the checked-in state of the reference's .bmp
+    // files) is skipped with a warning, leaving the material's flat diffuse colour.
+    std::map<std::string, int32_t> color_maps;            // map file name -> TexId (shared, builder.rs:127)
+    {
+        size_t slash = path.find_last_of('/');
+        const std::string dir = slash == std::string::npos ? std::string() : path.substr(0, slash + 1);
+        for (auto& kv : materials) {
+            const ObjMaterial& m = kv.second;
+            if (!m.has_map || color_maps.count(m.map)) continue;
+            rtimg::Image img; std::string err;
+            if (!rtimg::decode_file(dir + m.map, img, err)) {
+                if (img.lfs_pointer) { g_warning = "WARNING: colour map skipped (" + err + ")"; continue; }
+                g_error = err; return RT_E_IO;
+            }
+            color_maps[m.map] = (int32_t)b.add_color_map_rgba8(img.width, img.height, img.rgba.data());
+        }
+    }
     int mesh = (int)b.add_mesh(std::move(tris));
     // MeshTextureSet -> one MESH_SET texture over MESH textures
     std::vector<int32_t> entries;
     for (auto& n : names) {
         const ObjMaterial& m = materials[n];
         RtTexture t{}; t.kind = RT_TEX_MESH; t.color = out3(m.diffuse); t.color2 = out3(m.ambient); t.child0 = -1; t.child1 = -1;
+        if (m.has_map) { auto it = color_maps.find(m.map); if (it != color_maps.end()) t.child0 = it->second; }   // else: "Unable to find color map" (builder.rs:62-65)
         entries.push_back((int32_t)b.add_texture(t));
     }
     RtTexture set{}; set.kind = RT_TEX_MESH_SET; set.child0 = (int32_t)b.tex_set_entries.size(); set.child1 = (int32_t)entries.size();
@@ -803,6 +833,24 @@ int rt_builder_add_color_map(RtSceneBuilder* b, uint32_t w, uint32_t h, const fl
     for (uint64_t i = 0; i < (uint64_t)w * h; i++) b->texels.push_back(RtV3{rgbp[3 * i], rgbp[3 * i + 1], rgbp[3 * i + 2]});
     return (int)b->add_texture(t);
 }
+int rt_builder_load_color_map(RtSceneBuilder* b, const char* path) {
+    if (!b || !path) return RT_E_INVALID;
+    rtimg::Image img; std::string err;
+    if (!rtimg::decode_file(path, img, err)) { g_error = err; return RT_E_IO; }
+    return (int)b->add_color_map_rgba8(img.width, img.height, img.rgba.data());
+}
+int rt_image_decode(const char* path, uint32_t* width, uint32_t* height, uint8_t* rgba_out, uint64_t capacity) {
+    if (!path || !width || !height) return RT_E_INVALID;
+    rtimg::Image img; std::string err;
+    if (!rtimg::decode_file(path, img, err)) { g_error = err; return RT_E_IO; }
+    *width = img.width; *height = img.height;
+    if (rgba_out) {
+        if (capacity < img.rgba.size()) { g_error = "rt_image_decode: capacity too small"; return RT_E_INVALID; }
+        memcpy(rgba_out, img.rgba.data(), img.rgba.size());
+    }
+    return RT_OK;
+}
+const char* rt_samples_last_warning(void) { return g_warning.c_str(); }
 int rt_builder_add_light(RtSceneBuilder* b, const RtLight* l) { if (!b || !l) return RT_E_INVALID; b->add_light(*l); return (int)b->lights.size() - 1; }
 int rt_builder_add_mesh(RtSceneBuilder* b, const RtMeshTri* tris, uint64_t count) {
     if (!b || !tris || count == 0) return RT_E_INVALID;

@@ -8,6 +8,7 @@ of ``Scene::new`` + ``add_*``, ``Scene`` is the built scene resident on one GPU
 C ABI of include/rt_hip.h; this module only marshals arguments.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -165,6 +166,10 @@ class SceneBuilder:
         px = np.ascontiguousarray(pixels, dtype=np.float32)
         h, w, _ = px.shape
         return self._check(self._lib.rt_builder_add_color_map(self._h, w, h, px.ctypes.data))
+
+    def load_color_map(self, path):
+        """load_color_map(path), raytracer-obj/src/builder.rs:159-172: PNG / BMP file -> ColorMap TexId."""
+        return self._check(self._lib.rt_builder_load_color_map(self._h, os.fsencode(path)))
 
     def add_mesh_texture(self, ambient, diffuse, color_map_tex=-1):
         return self._tex(kind=_ffi.RT_TEX_MESH, color=_v3(diffuse), color2=_v3(ambient), child0=color_map_tex)
@@ -347,4 +352,16 @@ def v3_to_rgba(rgb):
     a = np.ascontiguousarray(rgb, dtype=np.float32)
     out = np.empty(a.shape[:-1] + (4,), dtype=np.uint8)
     lib.rt_v3_to_rgba(a.ctypes.data, a.size // 3, out.ctypes.data)
+    return out
+
+
+def decode_image(path):
+    """The colour-map decoder on its own: (H, W, 4) uint8, row 0 = top."""
+    lib = _ffi.load_samples()
+    w, h = C.c_uint32(), C.c_uint32()
+    if lib.rt_image_decode(os.fsencode(path), C.byref(w), C.byref(h), None, 0) != 0:
+        raise ValueError(lib.rt_samples_last_error().decode())
+    out = np.zeros((h.value, w.value, 4), dtype=np.uint8)
+    if lib.rt_image_decode(os.fsencode(path), C.byref(w), C.byref(h), out.ctypes.data, out.size) != 0:
+        raise ValueError(lib.rt_samples_last_error().decode())
     return out
