@@ -13,6 +13,7 @@
 #include "../../include/rt_samples.h"
 #include "image_decode.h"
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -790,16 +791,129 @@ int dootdoot(RtSceneBuilder& s, const Ctx& cx) {                                
     return RT_OK;
 }
 
+int spaceships(RtSceneBuilder& s, const Ctx& cx) {                                   // samples.rs:505-554
+    Vec look_from = pos(Up(350.0f), South(400.0f), East(700.0f)), look_to = pos(Down(50.0f), West(350.0f));
+    s.camera = make_camera(cx.cam, look_to, look_from); s.sky = RT_SKY_BLACK;
+    Vec lamp_pos = pos(Up(1000.0f), East(1000.0f));
+    s.add_light(directional_light(sub(kZero, lamp_pos), 0.9f));
+    float world_radius = 10000.0f;
+    uint32_t world_mat = s.add_material(lambertian()), world_tex = s.add_texture(color_texture(rgb(200, 200, 200)));
+    add_entity(s, EntityB::of(sphere(world_radius, world_mat, world_tex)).translate(pos(Down(world_radius), Down(1000.0f))).id(0));
+    int dest_set; int dest = load_mesh(s, cx, "Destroyer-K/Standarddestroyer.obj", &dest_set); if (dest < 0) return dest;
+    uint32_t dest_mat = s.add_material(lambertian());
+    EntityB dest_mesh = EntityB::of(mesh_object((uint32_t)dest, dest_mat, (uint32_t)dest_set)).rotate(kZ, deg_to_rad(90.0f));
+    int int_set; int intc = load_mesh(s, cx, "Interceptor-T/Heavyinterceptor.obj", &int_set); if (intc < 0) return intc;
+    uint32_t int_mat = s.add_material(lambertian());
+    EntityB int_mesh = EntityB::of(mesh_object((uint32_t)intc, int_mat, (uint32_t)int_set)).rotate(kZ, deg_to_rad(90.0f));
+    Vec int_origin = add(look_to, pos(Up(200.0f), East(300.0f), South(30.0f)));
+    { EntityB e = int_mesh; add_entity(s, e.translate(add(int_origin, pos(East(15.0f))))); }
+    { EntityB e = int_mesh; add_entity(s, e.translate(add(int_origin, pos(East(2.0f), North(80.0f), Down(30.0f))))); }
+    { EntityB e = int_mesh; add_entity(s, e.translate(add(int_origin, pos(East(1.0f), South(65.0f), Down(15.0f))))); }
+    add_entity(s, dest_mesh.translate(look_to));
+    return RT_OK;
+}
+
+// scene_interceptor_spin.rs:32-77.  The reference takes the angle from the wall clock;
+// "Time Ms" (not a control of the reference) pins it for reproducible renders.
+int interceptor_spin(RtSceneBuilder& s, const Ctx& cx) {
+    float ms_per_rotation = cx.params.get("Seconds Per Rotation", 10.0f) * 1000.0f;
+    unsigned __int128 ms_since_epoch;
+    if (cx.params.values.count("Time Ms")) ms_since_epoch = (unsigned __int128)cx.params.get("Time Ms", 0.0f);
+    else ms_since_epoch = (unsigned __int128)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::system_clock::now().time_since_epoch()).count();
+    unsigned __int128 period = (unsigned __int128)ms_per_rotation;      // `as u128` truncates (saturating)
+    if (period == 0) { g_error = "Seconds Per Rotation: attempt to calculate the remainder with a divisor of zero"; return RT_E_INVALID; }
+    float rot_rads = ((float)(ms_since_epoch % period) / ms_per_rotation) * kPi * 2.0f;
+    float dist = cx.params.get("Camera Distance", 100.0f);
+    Vec look_to = kZero, look_from = scale(kOne, dist);
+    s.camera = make_camera(cx.cam, look_to, look_from); s.sky = RT_SKY_BLACK;
+    s.add_light(point_light(add(look_from, scale(kY, 1000.0f)), cx.params.get("Global Light Intensity", 20.0f)));
+    Vec spot = add(look_from, divide(scale(kY, dist), 10.0f));
+    s.add_light(lamp_light(spot, sub(look_to, spot), cx.params.get("Spotlight Intensity", 1200.0f), cx.params.get("Spotlight Beam Angle", 60.0f)));
+    int tex_set; int mesh = load_mesh(s, cx, "Interceptor-T/Heavyinterceptor.obj", &tex_set); if (mesh < 0) return mesh;
+    uint32_t mat = s.add_material(lambertian());
+    add_entity(s, EntityB::of(mesh_object((uint32_t)mesh, mat, (uint32_t)tex_set)).rotate(kY, rot_rads).rotate(kZ, deg_to_rad(90.0f)));
+    return RT_OK;
+}
+
+// CheckerTexture::new(size, ColorTexture(odd), ColorTexture(even)), texture.rs:20-30
+RtTexture checker_texture(RtSceneBuilder& s, float size, Vec odd, Vec even) {
+    RtTexture t{}; t.kind = RT_TEX_CHECKER; t.size = size;
+    t.child0 = (int32_t)s.add_texture(color_texture(odd)); t.child1 = (int32_t)s.add_texture(color_texture(even));
+    return t;
+}
+
+// scene_entity_transform_test.rs:88-118
+float hue_to_rgb(float p, float q, float t) {
+    if (t < 0.0f) t += 1.0f;
+    if (t > 1.0f) t -= 1.0f;
+    if (t < 1.0f / 6.0f) return p + (q - p) * 6.0f * t;
+    if (t < 1.0f / 2.0f) return q;
+    if (t < 2.0f / 3.0f) return p + (q - p) * (2.0f / 3.0f - t) * 6.0f;
+    return p;
+}
+Vec hsl_to_rgb(float h, float sat, float l) {
+    if (sat == 0.0f) return mk(1.0f, 1.0f, 1.0f);
+    float q = l < 0.5f ? l * (1.0f + sat) : l + sat - l * sat;
+    float p = 2.0f * l - q;
+    return mk(hue_to_rgb(p, q, h + 1.0f / 3.0f), hue_to_rgb(p, q, h), hue_to_rgb(p, q, h - 1.0f / 3.0f));
+}
+
+int entity_transform_test(RtSceneBuilder& s, const Ctx& cx) {                        // scene_entity_transform_test.rs:34-85
+    Vec look_from = add(add(kZero, scale(mk(0, 0, -1), 100.0f)), scale(kY, 100.0f)), look_to = kZero;
+    s.camera = make_camera(cx.cam, look_to, look_from); s.sky = RT_SKY_DAY;
+    uint32_t lamb = s.add_material(lambertian());
+    uint32_t checker = s.add_texture(checker_texture(s, cx.params.get("Plane Checker Scale", 1.0f), mk(1.0f, 0.5f, 0.5f), mk(0.5f, 1.0f, 0.5f)));
+    Vec lamp_pos = scale(kY, cx.params.get("Lamp Height", 10.0f));
+    s.add_light(lamp_light(lamp_pos, sub(look_to, lamp_pos), cx.params.get("Lamp Intensity", 400.0f), cx.params.get("Lamp Angle", 120.0f)));
+    add_entity(s, EntityB::of(plane_new(kY, lamb, checker)).translate(scale(mk(0, -1, 0), 0.5f)).translate(scale(kX, 0.5f))
+                      .rotate(kY, deg_to_rad(cx.params.get("Plane Rotation Deg", 0.0f))).id(1));
+    float additional_rot = cx.params.get("Swirl Rotation Deg", 0.0f);
+    SceneRng rng((unsigned __int128)138219031u);
+    for (int i = 0; i < 1000; i++) {
+        float dist = rng.random_f32(), angle = rng.random_f32();
+        Vec translation = rotated(scale(scale(kX, dist), 50.0f), kY, (angle * 2.0f * kPi) + deg_to_rad(additional_rot));
+        uint32_t tex = s.add_texture(color_texture(hsl_to_rgb(angle, dist, 0.6f)));
+        add_entity(s, EntityB::of(sphere(1.0f, lamb, tex)).translate(translation));
+    }
+    return RT_OK;
+}
+
+int uv_test(RtSceneBuilder& s, const Ctx& cx) {                                      // scene_uv_test.rs:33-106
+    Vec look_from = add(add(kZero, scale(mk(0, 0, -1), 2.0f)), scale(kY, 2.0f)), look_to = kZero;
+    s.camera = make_camera(cx.cam, look_to, look_from); s.sky = RT_SKY_DAY;
+    uint32_t lamb = s.add_material(lambertian());
+    Vec lamp_pos = add(look_from, scale(kY, 5.0f));
+    s.add_light(lamp_light(lamp_pos, sub(look_to, lamp_pos), 80.0f, 60.0f));
+    uint32_t plane_tex = s.add_texture(checker_texture(s, cx.params.get("Plane Checker Scale", 1.0f), mk(1.0f, 0.5f, 0.5f), mk(0.5f, 1.0f, 0.5f)));
+    Vec plane_origin = add(add(add(look_to, scale(kY, cx.params.get("Plane Offset Y", -0.5f))), scale(kX, cx.params.get("Plane Offset X", 0.0f))),
+                           scale(kZ, cx.params.get("Plane Offset Z", 0.0f)));
+    add_entity(s, EntityB::of(plane_new(kY, lamb, plane_tex)).translate(plane_origin).rotate(kY, deg_to_rad(cx.params.get("Plane Rotation Deg", 0.0f))).id(1));
+    // load_color_map(mesh_path!("simple/test.bmp"))?: no skipping here, a file that does not decode fails the scene
+    rtimg::Image img; std::string err;
+    if (!rtimg::decode_file(cx.mesh_dir + "/simple/test.bmp", img, err)) { g_error = err; return RT_E_IO; }
+    uint32_t mesh_tex = s.add_color_map_rgba8(img.width, img.height, img.rgba.data());
+    int mesh = load_mesh(s, cx, "simple/plane.obj", nullptr); if (mesh < 0) return mesh;
+    float ry = cx.params.get("Mesh Rotation Y Deg", 0.0f), rx = cx.params.get("Mesh Rotation X Deg", -40.0f);
+    add_entity(s, EntityB::of(mesh_object((uint32_t)mesh, lamb, mesh_tex)).translate(add(look_to, scale(kY, 0.5f)))
+                      .rotate(kY, deg_to_rad(180.0f)).rotate(kY, deg_to_rad(ry)).rotate(kX, deg_to_rad(rx)).id(2));
+    RtTexture uvt{}; uvt.kind = RT_TEX_UV_TEST; uvt.child0 = uvt.child1 = -1;
+    uint32_t uv_tex = s.add_texture(uvt);
+    add_entity(s, EntityB::of(mesh_object((uint32_t)mesh, lamb, uv_tex)).translate(add(add(add(look_to, scale(kY, 0.5f)), scale(kX, 1.0f)), scale(mk(0, 0, -1), 0.5f)))
+                      .rotate(kY, deg_to_rad(180.0f + 45.0f)).rotate(kY, deg_to_rad(ry)).rotate(kX, deg_to_rad(rx)).id(3));
+    add_entity(s, EntityB::of(mesh_object((uint32_t)mesh, lamb, uv_tex)).translate(add(add(add(look_to, scale(kY, 0.5f)), scale(mk(-1, 0, 0), 1.0f)), scale(mk(0, 0, -1), 0.5f)))
+                      .rotate(kY, deg_to_rad(180.0f - 45.0f)).rotate(kY, deg_to_rad(ry)).rotate(kX, deg_to_rad(rx)).id(4));
+    return RT_OK;
+}
+
 typedef int (*Factory)(RtSceneBuilder&, const Ctx&);
 struct Named { const char* name; Factory fn; };
-// lib.rs:18-37 order; the scenes whose only content is missing BMP textures or
-// wall-clock time ("Spaceships", "Interceptor Spin", the two visual test
-// scenes) are not listed.
+// lib.rs:18-37, same order and names
 const Named kFactories[] = {
     {"Random Spheres", random_sphere_scene}, {"Simple", simple_scene}, {"Planes", planes_scene},
     {"Mirrors", hall_of_mirrors}, {"Triangles", triangle_world}, {"Mesh", mesh_demo}, {"Capsule", capsule},
-    {"Point Cloud", point_cloud}, {"Mega Cube", mega_cube}, {"Fleet", fleet},
-    {"Dreadnaught", dreadnaught}, {"Doot Doot", dootdoot},
+    {"Point Cloud", point_cloud}, {"Mega Cube", mega_cube}, {"Spaceships", spaceships}, {"Fleet", fleet},
+    {"Interceptor Spin", interceptor_spin}, {"Dreadnaught", dreadnaught}, {"Doot Doot", dootdoot},
+    {"Entity Transforms Test", entity_transform_test}, {"UV Test", uv_test},
 };
 const int kFactoryCount = (int)(sizeof(kFactories) / sizeof(kFactories[0]));
 

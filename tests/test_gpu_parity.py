@@ -77,6 +77,10 @@ def test_primary_hits_match_oracle(name, w, h):
     ("Planes", 160, 90, 2, 5),
     ("Mirrors", 160, 90, 2, 10),
     ("Triangles", 160, 90, 1, 5),
+    ("UV Test", 160, 90, 2, 5),                 # ColorMap + UvTestTexture on rotated mesh planes, checker plane
+    ("Entity Transforms Test", 160, 90, 2, 5),  # 1000 translated spheres over a translated + rotated plane
+    ("Spaceships", 160, 90, 1, 5),              # two OBJ meshes, four instances, rotated
+    ("Capsule", 120, 68, 1, 5),
 ])
 def test_image_matches_oracle(name, w, h, spp, depth):
     b, scene, oracle = make(name, w, h)
@@ -94,6 +98,21 @@ def test_image_matches_oracle(name, w, h, spp, depth):
     assert abs(cn.shadow - rcn.rays.shadow) <= max(4, 2e-3 * rcn.rays.shadow)
     # bytes: (255*c) as u8 flips on a last-ulp difference only
     assert (np.abs(rgba.astype(int) - ref_rgba.astype(int)) > 1).mean() <= IMAGE_OUTLIER_FRAC
+
+
+def test_scene_controls_reach_the_scene():
+    """SceneControl parameters (raytracer-samples/src/scene.rs) change the scene on both sides alike."""
+    w, h = 128, 72
+    st, ch = RenderSettings(w, h, 5, 2), RenderChunk(0, 0, w, h)
+    frames = []
+    for params in ({"Time Ms": 0, "Camera Distance": 60}, {"Time Ms": 2500, "Camera Distance": 60}):
+        b, scene, oracle = make("Interceptor Spin", w, h, params=params)
+        rgb, _, cn = scene.render_chunk(st, ch, seed=12345)
+        ref, _, rcn = oracle.render_chunk(st, ch, ORC_RNG_COUNTER, 12345, sum_segment=sample_segment())
+        check_image(rgb, ref)
+        assert cn.primary == rcn.rays.primary
+        frames.append(rgb)
+    assert not np.array_equal(frames[0], frames[1])      # a quarter turn later
 
 
 def test_image_independent_of_chunking():

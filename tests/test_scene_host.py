@@ -18,9 +18,50 @@ def sample(name, w=64, h=36):
 
 
 def test_sample_scene_list():
-    names = SceneBuilder.sample_names()
-    for n in ("Random Spheres", "Mesh", "Dreadnaught", "Doot Doot", "Fleet", "Simple", "Planes", "Mirrors"):
-        assert n in names
+    # make_sample_scene_factories, raytracer-samples/src/lib.rs:18-37: same names, same order
+    assert SceneBuilder.sample_names() == [
+        "Random Spheres", "Simple", "Planes", "Mirrors", "Triangles", "Mesh", "Capsule", "Point Cloud", "Mega Cube", "Spaceships",
+        "Fleet", "Interceptor Spin", "Dreadnaught", "Doot Doot", "Entity Transforms Test", "UV Test"]
+
+
+def test_entity_transform_test_scene_shape():
+    # scene_entity_transform_test.rs:58-82: a twice-translated, rotated plane + 1000 unit spheres within 50 of the y axis
+    b = SceneBuilder.sample("Entity Transforms Test", CameraConfiguration(64, 36), params={"Plane Rotation Deg": 30})
+    d = b.desc().contents
+    assert d.entity_count == 1001 and d.plane_count == 1 and d.sphere_count == 1000 and d.light_count == 1
+    e0 = d.entities[0]
+    assert (e0.hitable_kind, e0.id, e0.translation_count, e0.rotation_count) == (_ffi.RT_HITABLE_PLANE, 1, 2, 1)
+    assert d.translations[e0.translation_first].y == -0.5 and d.translations[e0.translation_first + 1].x == 0.5
+    for i in range(1, 1001):
+        t = d.translations[d.entities[i].translation_first]
+        assert t.y == 0.0 and t.x * t.x + t.z * t.z <= 50.0 * 50.0 * 1.0001
+    cols = np.array([[d.textures[d.spheres[i].tex_id].color.x, d.textures[d.spheres[i].tex_id].color.y, d.textures[d.spheres[i].tex_id].color.z] for i in range(1000)])
+    assert cols.min() >= 0.0 and cols.max() <= 1.0 and len(np.unique(cols.round(3), axis=0)) > 900      # hsl_to_rgb swirl
+
+
+def test_uv_test_scene_shape():
+    # scene_uv_test.rs:64-103: checker plane + one plane.obj mesh instanced three times, ids 1..4, three rotations each
+    b = SceneBuilder.sample("UV Test", CameraConfiguration(64, 36))
+    d = b.desc().contents
+    assert d.entity_count == 4 and d.mesh_count == 1 and d.meshes[0].tri_count == 2
+    assert [d.entities[i].id for i in range(4)] == [1, 2, 3, 4]
+    assert [d.entities[i].rotation_count for i in range(4)] == [1, 3, 3, 3]
+    kinds = [d.textures[d.mesh_objects[i].tex_id].kind for i in range(3)]
+    assert kinds == [_ffi.RT_TEX_COLOR_MAP, _ffi.RT_TEX_UV_TEST, _ffi.RT_TEX_UV_TEST]
+    assert d.texel_count == 256 * 256
+
+
+def test_interceptor_spin_angle_follows_the_clock_parameter():
+    # scene_interceptor_spin.rs:34-40: angle = (ms % period) / period * 2 pi; "Time Ms" stands in for SystemTime::now()
+    def angle(ms, spr=10):
+        b = SceneBuilder.sample("Interceptor Spin", CameraConfiguration(64, 36), params={"Time Ms": ms, "Seconds Per Rotation": spr})
+        d = b.desc().contents
+        assert d.entities[0].rotation_count == 2
+        return d.rotations[d.entities[0].rotation_first].theta
+    assert angle(0) == 0.0
+    assert angle(2500) == np.float32(np.float32(0.25) * np.float32(np.pi) * np.float32(2.0))
+    assert angle(12500) == angle(2500)
+    assert angle(2500, 20) == np.float32(np.float32(0.125) * np.float32(np.pi) * np.float32(2.0))
 
 
 def test_weekend_scene_shape():
@@ -79,7 +120,8 @@ def test_obj_missing_file_is_an_error():
 
 
 @pytest.mark.parametrize("name", ["Random Spheres", "Simple", "Planes", "Mirrors", "Triangles", "Mesh", "Mega Cube",
-                                  "Fleet", "Dreadnaught", "Doot Doot", "Point Cloud"])
+                                  "Fleet", "Dreadnaught", "Doot Doot", "Point Cloud", "Capsule", "Spaceships",
+                                  "Interceptor Spin", "Entity Transforms Test", "UV Test"])
 def test_bvh_build_matches_oracle(name):
     """Two independent implementations of bvh.rs:129-188 + util.rs:6-28 (the product's
     SoA/permutation builder and the oracle's restatement) must agree on the order in
