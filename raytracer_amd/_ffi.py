@@ -228,6 +228,13 @@ def load_hip():
         if not os.path.exists(path):
             raise ImportError(f"{path} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(the render core has no CPU fallback)")
+        # One HIP runtime per process: PyTorch ships its own libamdhip64, and if librt_hip.so
+        # pulls in /opt/rocm's first, torch afterwards finds no usable GPU ("No HIP GPUs are
+        # available").  With torch loaded first both share torch's runtime.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         _hip_lib = _bind(C.CDLL(path), HIP_PROTOTYPES)
     return _hip_lib
 

@@ -47,7 +47,9 @@
 #ifndef RT_SAMPLE_SEGMENT
 #define RT_SAMPLE_SEGMENT 8u
 #endif
+#ifndef RT_BLOCK
 #define RT_BLOCK 256
+#endif
 #define RT_PENDING_MAX 8
 #ifndef RT_WAVES_PER_SIMD
 #define RT_WAVES_PER_SIMD 4     /* register budget of the render kernel: 512 / 4 -> 128 VGPRs */
