@@ -152,6 +152,7 @@ def main():
     scene.profile_enable(False)
 
     cn = counters.clone()
+    local_rays = int(cn[:3].sum().item())          # this rank's rays: what its own kernel launches traced
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if distributed:
         dist.all_reduce(cn, op=dist.ReduceOp.SUM)
@@ -178,8 +179,8 @@ def main():
                               "shadow": shadow // args.steps},
         }
 
-    # ---- oracle legs: rank 0, N = 1 only -----------------------------------------
-    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
+    # ---- oracle legs on rank 0: (1) roofline statistics at any N ---------------------------------------
+    if rank == 0 and not args.no_cpu_baseline:
         from tests.oracle import ORC_RNG_COUNTER, ORC_RNG_XORSHIFT_CHUNK, OracleScene
         oracle = OracleScene(builder)
         grid = (32, 32)
@@ -199,12 +200,12 @@ def main():
         gather_bytes_per_ray = (per_ray["nodes"] * B_NODE + (per_ray["spheres"] + per_ray["planes"]) * B_ENTITY +
                                 per_ray["tris"] * B_TRI + per_ray["instances"] * B_INST + B_RAY)
         kernel_s = kernel_ms / 1e3 / max(launches, 1)
-        rays_per_launch = rays / max(launches, 1)
+        rays_per_launch = local_rays / max(launches, 1)     # rank 0's launches (N > 1: its share of the frame)
         tflops = flops_per_ray * rays_per_launch / kernel_s / 1e12
         # algorithmic HBM bytes of one launch: the scene once + one float3 segment sum per work item
         from raytracer_amd import sample_segment
         segs = (spp + sample_segment() - 1) // sample_segment()
-        hbm_bytes_per_launch = (int(info.device_bytes) + W * H * segs * B_PIXEL) * (args.steps / max(launches, 1))
+        hbm_bytes_per_launch = (int(info.device_bytes) + W * H * segs * B_PIXEL // n_gpus) * (args.steps / max(launches, 1))
         gbs = hbm_bytes_per_launch / kernel_s / 1e9
         traffic = None
         pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # HBM bytes per launch from rocprofv3 --pmc passes
@@ -215,7 +216,7 @@ def main():
                 traffic = None
         result["roofline"] = {
             "bound": "valu", "achieved": round(tflops, 4), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(tflops / VALU_PEAK_TFLOPS, 5), "traffic": traffic,
+            "frac": round(tflops / VALU_PEAK_TFLOPS, 5), "traffic": traffic if n_gpus == 1 else None,
             "kernel": "render_kernel", "kernel_ms_avg": round(kernel_s * 1e3, 4), "launches": int(launches),
             "flops_per_ray": round(flops_per_ray, 2),
             "per_ray": {k: round(v, 3) for k, v in per_ray.items()}, "traversal_mismatch": int(cn_s.min_mismatch),
@@ -225,7 +226,8 @@ def main():
                                   "scene_bytes": int(info.device_bytes),
                                   "on_chip_gather_bytes_per_ray": round(gather_bytes_per_ray, 2),
                                   "on_chip_gather_GBps": round(gather_bytes_per_ray * rays_per_launch / kernel_s / 1e9, 1)}
-        # (2) the reference's multithreaded CPU path, bounded sample of the same frame
+    # (2) the reference's multithreaded CPU path, bounded sample of the same frame: N = 1 only
+    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         # about 6e8 samples (10-20 s on 16 host threads)
         stride = args.cpu_chunk_stride or max(1, int(round(W * H * spp / 6.0e8)))
         count = (n_chunks - 1) // stride
