@@ -1,0 +1,153 @@
+"""GPU parity on the edges of the path: hand-built scenes through the generic builder
+(Scene::add_*), ragged sample counts and chunks, depth limits, argument errors.
+Same tolerances as tests/test_gpu_parity.py; every comparison is against the oracle."""
+import numpy as np
+import pytest
+
+from raytracer_amd import RenderChunk, RenderSettings, RtError, Scene, SceneBuilder, _ffi, camera_new, sample_segment
+from tests.oracle import ORC_RNG_COUNTER, OracleScene
+from tests.test_gpu_parity import check_image, check_primary
+
+pytestmark = pytest.mark.gpu
+
+W, H = 96, 54
+
+
+def camera(lens_radius=0.0, look_from=(0.0, 1.5, 6.0)):
+    return camera_new(look_from, (0, 0.5, 0), 45.0, W / H, lens_radius, 6.0)
+
+
+def both(b):
+    return Scene(b, 0), OracleScene(b)
+
+
+def compare(b, depth=5, spp=2, seed=9, chunk=None, **tol):
+    scene, oracle = both(b)
+    st, ch = RenderSettings(W, H, depth, spp), chunk or RenderChunk(0, 0, W, H)
+    rgb, rgba, cn = scene.render_chunk(st, ch, seed=seed)
+    ref, ref_rgba, rcn = oracle.render_chunk(st, ch, ORC_RNG_COUNTER, seed, sum_segment=sample_segment())
+    check_image(rgb, ref, **tol)
+    assert (cn.primary, cn.samples) == (rcn.rays.primary, rcn.rays.samples)
+    return rgb, cn, rcn
+
+
+def basic_scene(sky=_ffi.RT_SKY_DAY, light=True, lens_radius=0.0):
+    b = SceneBuilder(camera(lens_radius), sky)
+    m, t = b.add_lambertian(), b.add_color_texture((0.8, 0.3, 0.2))
+    g = b.add_color_texture((0.5, 0.5, 0.5))
+    b.add_sphere_entity(1.0, m, t, translations=[(0, 1, 0)], id=7)
+    b.add_sphere_entity(100.0, m, g, translations=[(0, -100, 0)])
+    if light:
+        b.add_directional_light((-1, -3, -1), 0.8)
+    return b
+
+
+def test_scene_without_lights():
+    # implementation.rs:608-621: the light loop is empty, colour = reflections only (none here): black objects on sky
+    rgb, cn, _ = compare(basic_scene(light=False))
+    assert cn.shadow == 0 and rgb.max() > 0.5 and rgb.min() == 0.0
+
+
+def test_depth_zero_is_sky_only():
+    # cast_ray_recursive at limit 0 returns the sky without casting (implementation.rs:562-564)
+    rgb, cn, rcn = compare(basic_scene(), depth=0)
+    assert cn.primary == 0 and cn.shadow == 0 and rcn.rays.primary == 0
+    assert rgb.min() > 0.4
+
+
+def test_depth_one_and_maximum_depth():
+    b = SceneBuilder(camera(), _ffi.RT_SKY_DAY)
+    mirror, white = b.add_specular(0.95, 0.0), b.add_color_texture((1, 1, 1))
+    glass, tint = b.add_dielectric(1.0, 0.1, 1.5), b.add_color_texture((0.9, 1.0, 0.9))
+    b.add_plane_entity((1, 0, 0), mirror, white, translations=[(-2, 0, 0)])
+    b.add_plane_entity((-1, 0, 0), mirror, white, translations=[(2, 0, 0)])
+    b.add_sphere_entity(0.8, glass, tint, translations=[(0, 0.8, 0)])
+    b.add_sphere_entity(100.0, b.add_lambertian(), b.add_color_texture((0.4, 0.4, 0.6)), translations=[(0, -100, 0)])
+    b.add_point_light((0, 5, 3), 60.0)
+    compare(b, depth=1)
+    _, cn, rcn = compare(b, depth=31, spp=1)          # RT_MAX_REFLECTIONS: reflection/refraction budget split all the way down
+    assert cn.secondary > 3 * cn.primary
+    assert abs(cn.secondary - rcn.rays.secondary) <= max(4, 2e-3 * rcn.rays.secondary)
+    scene, _ = both(b)
+    with pytest.raises(RtError, match="max_reflections"):
+        scene.render_chunk(RenderSettings(W, H, 32, 1), RenderChunk(0, 0, W, H))
+
+
+@pytest.mark.parametrize("spp", [1, 7, 8, 9, 17])
+def test_ragged_sample_counts(spp):
+    # the last sample segment is partial unless spp is a multiple of rt_sample_segment()
+    compare(basic_scene(lens_radius=0.2), spp=spp)
+
+
+@pytest.mark.parametrize("chunk", [(0, 0, 1, 1), (W - 1, H - 1, 1, 1), (5, 0, 1, H), (0, 13, W, 1), (3, 2, 9, 10), (W - 13, H - 11, 13, 11)])
+def test_ragged_chunks_are_cut_from_the_same_frame(chunk):
+    b = basic_scene(lens_radius=0.2)
+    scene, _ = both(b)
+    st = RenderSettings(W, H, 4, 3)
+    whole, whole8, _ = scene.render_chunk(st, RenderChunk(0, 0, W, H), seed=4)
+    l, t, w, h = chunk
+    part, part8, cn = scene.render_chunk(st, RenderChunk(l, t, w, h), seed=4)
+    assert np.array_equal(part, whole[t:t + h, l:l + w]) and np.array_equal(part8, whole8[t:t + h, l:l + w])
+    assert cn.samples == w * h * 3
+
+
+def test_argument_errors():
+    scene, _ = both(basic_scene())
+    ok = RenderSettings(W, H, 3, 1)
+    for st, ch, what in [(ok, RenderChunk(0, 0, 0, 4), "empty chunk"), (ok, RenderChunk(W - 3, 0, 4, 4), "outside"),
+                         (ok, RenderChunk(0, H, 1, 1), "outside"), (RenderSettings(W, H, 3, 0), RenderChunk(0, 0, 4, 4), "must be > 0"),
+                         (RenderSettings(70000, H, 3, 1), RenderChunk(0, 0, 4, 4), "65535")]:
+        with pytest.raises(RtError, match=what):
+            scene.render_chunk(st, ch)
+    with pytest.raises(RtError, match="out of range"):
+        Scene(basic_scene(), 99)
+    again, _, _ = scene.render_chunk(ok, RenderChunk(0, 0, 8, 8))       # the scene is still usable after errors
+    assert again.shape == (8, 8, 3)
+
+
+def test_stacked_transforms_on_every_hitable():
+    # Entity::hit (implementation.rs:285-310): translations summed, rotations applied in order about arbitrary
+    # axes, including exact identities (theta 0 and the axis-aligned case the kernel skips)
+    b = SceneBuilder(camera(), _ffi.RT_SKY_DAY)
+    m = b.add_lambertian(0.1)
+    red, blue, chk = b.add_color_texture((0.9, 0.2, 0.2)), b.add_color_texture((0.2, 0.2, 0.9)), None
+    chk = b.add_checker_texture(3.0, red, blue)
+    tri = np.array([[[-1, 0, 0], [1, 0, 0], [0, 1.5, 0]], [[-1, 0, 0], [0, 1.5, 0], [0, 0.5, -1]]], dtype=np.float32)
+    mesh = b.add_mesh(tri, uvs=[[(0, 0), (1, 0), (0.5, 1)], [(0, 0), (0.5, 1), (1, 1)]])
+    axis = (0.3, 0.9, 0.1)
+    b.add_mesh_entity(mesh, m, b.add_uv_test_texture(), translations=[(1.5, 0, 0), (0, 0.2, 0.3)],
+                      rotations=[((0, 1, 0), 0.7), (axis, -0.4), ((1, 0, 0), 0.0)], id=1)
+    b.add_mesh_entity(mesh, m, red, translations=[(-1.5, 0.1, 0)], rotations=[((0, 0, 1), 0.0), ((0, 1, 0), 2.5)], id=2)
+    b.add_sphere_entity(0.5, m, b.add_xyz_test_texture(2.0), translations=[(0, 0.5, 1), (0.1, 0, 0), (0, 0.2, 0)], rotations=[(axis, 1.1)], id=3)
+    b.add_plane_entity((0, 1, 0), m, chk, translations=[(0, -0.2, 0), (0.5, 0, 0)], rotations=[((0, 1, 0), 0.6)], id=4)
+    b.add_plane_entity((0, 0, 1), m, blue, radius=1.2, translations=[(0, 1.0, -2.5)], rotations=[((1, 0, 0), -0.3)], id=5)
+    b.add_lamp_light((2, 6, 4), (-2, -6, -4), 90.0, 40.0)
+    b.add_point_light((-3, 4, 2), 30.0)
+    scene, oracle = both(b)
+    exact, cover = check_primary(scene, oracle, RenderSettings(W, H, 8, 1), RenderChunk(0, 0, W, H))
+    assert exact > 0.999 and cover > 0.5
+    compare(b, depth=6, spp=3)
+
+
+def test_degenerate_geometry_does_not_disturb_the_rest():
+    # a zero-area triangle (normal = 0: |denominator| < 1e-6 rejects it, plane.rs:7-10) and a zero-radius sphere
+    b = SceneBuilder(camera(), _ffi.RT_SKY_BLACK)
+    m, t = b.add_lambertian(), b.add_color_texture((0.7, 0.7, 0.2))
+    tri = np.array([[[0, 0, 0], [1, 1, 1], [2, 2, 2]], [[-1, 0, 0], [1, 0, 0], [0, 1.5, 0]]], dtype=np.float32)
+    b.add_mesh_entity(b.add_mesh(tri), m, t)
+    b.add_sphere_entity(0.0, m, t, translations=[(0, 0.5, 2)])
+    b.add_point_light((0, 3, 5), 40.0)
+    scene, oracle = both(b)
+    check_primary(scene, oracle, RenderSettings(W, H, 4, 1), RenderChunk(0, 0, W, H))
+    rgb, _, _ = compare(b, depth=3, spp=1)
+    assert np.isfinite(rgb).all()
+
+
+def test_point_cloud_large_tlas():
+    # scene_point_cloud.rs: 200 000 spheres -> a deep TLAS (stack depth, tie ranks at scale)
+    from raytracer_amd import CameraConfiguration
+    b = SceneBuilder.sample("Point Cloud", CameraConfiguration(W, H, lens_radius=0.0), params={"Cloud Point Count": 200000})
+    scene, oracle = both(b)
+    assert scene.info().tlas_depth >= 17
+    exact, _ = check_primary(scene, oracle, RenderSettings(W, H, 4, 1), RenderChunk(0, 0, W, H))
+    assert exact > 0.999
