@@ -15,7 +15,12 @@
  *     otherwise; rt_last_error() then gives a thread-local message.  Nothing
  *     throws or aborts across this boundary.
  *   - `RtScene*` is opaque, immutable after creation and may be used from
- *     several host threads at once (calls are serialised per scene).
+ *     several host threads at once.  The host-pointer entry points
+ *     (rt_render_chunk, rt_primary_hits) each borrow a private workspace and
+ *     stream (up to 8 per scene, later callers wait), so the reference's worker
+ *     threads (src/render.rs:186-224) overlap on the GPU.  The *_device entry
+ *     points enqueue on the CALLER's stream and share one workspace per scene:
+ *     keep them on one stream (or use one scene per stream).
  *   - output buffers are caller allocated.
  */
 #ifndef RT_HIP_H

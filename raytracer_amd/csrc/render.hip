@@ -28,6 +28,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <utility>
@@ -1050,6 +1052,22 @@ struct DeviceBuffer {
 
 }  // namespace
 
+// Everything one in-flight render call writes besides the caller's outputs.
+struct Workspace {
+    hipStream_t stream = nullptr;    // own stream (host-pointer entry points only)
+    DeviceBuffer partial, accum, out_rgb, out_rgba, ctrl, prim;
+    int init(bool with_stream) {
+        if (with_stream) HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        return ctrl.ensure(256);
+    }
+    void release() {
+        if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); stream = nullptr; }
+        partial.release(); accum.release(); out_rgb.release(); out_rgba.release(); ctrl.release(); prim.release();
+    }
+};
+
+#define RT_MAX_WORKSPACES 8
+
 struct RtScene {
     int device = 0;
     DevSceneView view{};
@@ -1057,14 +1075,51 @@ struct RtScene {
     std::vector<uint32_t> tlas_order;
     std::vector<std::vector<uint32_t>> blas_order;
     std::vector<void*> allocations;
-    std::mutex lock;                 // serialises calls per scene
-    hipStream_t stream = nullptr;    // used by the host-pointer entry points
-    DeviceBuffer partial, accum, out_rgb, out_rgba, ctrl, prim;
+    // Device-pointer entry points run on the CALLER's stream and share this workspace:
+    // `lock` serialises their enqueueing, the caller keeps them on one stream.
+    std::mutex lock;
+    Workspace shared;
+    // Host-pointer entry points (rt_render_chunk, rt_primary_hits) each borrow a workspace
+    // with its own stream, so that calls from several host threads (the reference's
+    // worker threads, src/render.rs:186-224) overlap on the GPU.
+    std::mutex pool_lock;
+    std::condition_variable pool_cv;
+    std::vector<std::unique_ptr<Workspace>> pool;
+    std::vector<Workspace*> pool_free;
     int grid_blocks = 0;
     size_t lds_bytes = 0;
+    std::mutex profile_lock;
     bool profiling = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> profile_events;
 };
+
+namespace {
+
+// Borrows a workspace for the duration of one host-pointer call.
+struct WorkspaceLease {
+    RtScene* scene; Workspace* ws = nullptr; int rc = RT_OK;
+    explicit WorkspaceLease(RtScene* s) : scene(s) {
+        std::unique_lock<std::mutex> g(s->pool_lock);
+        for (;;) {
+            if (!s->pool_free.empty()) { ws = s->pool_free.back(); s->pool_free.pop_back(); return; }
+            if (s->pool.size() < RT_MAX_WORKSPACES) {
+                std::unique_ptr<Workspace> w(new Workspace());
+                rc = w->init(true);
+                if (rc) { w->release(); return; }
+                ws = w.get(); s->pool.push_back(std::move(w));
+                return;
+            }
+            s->pool_cv.wait(g);
+        }
+    }
+    ~WorkspaceLease() {
+        if (!ws) return;
+        { std::lock_guard<std::mutex> g(scene->pool_lock); scene->pool_free.push_back(ws); }
+        scene->pool_cv.notify_one();
+    }
+};
+
+}  // namespace
 
 namespace {
 
@@ -1095,7 +1150,7 @@ int validate_call(const RtScene* scene, const RtSettings* st, const RtRenderChun
 // into `acc` (float3 image with pitch acc_pitch, chunk origin at acc_x/acc_y).
 struct Interleave { uint32_t strip_h = 0, period_rows = 0, first_row = 0; };
 
-int enqueue_accumulate(RtScene* scene, const RtSettings* st, const RtRenderChunk* ch, uint64_t seed, uint32_t sample_first,
+int enqueue_accumulate(RtScene* scene, Workspace& ws, const RtSettings* st, const RtRenderChunk* ch, uint64_t seed, uint32_t sample_first,
                        uint32_t sample_count, float* acc, uint32_t acc_pitch, uint32_t acc_x, uint32_t acc_y, bool init_zero,
                        unsigned long long* counters_dev, hipStream_t stream, Interleave il = Interleave()) {
     if (sample_count == 0 || (uint64_t)sample_first + sample_count > st->samples_per_pixel) return set_error(RT_E_INVALID, "sample range outside samples_per_pixel");
@@ -1107,7 +1162,7 @@ int enqueue_accumulate(RtScene* scene, const RtSettings* st, const RtRenderChunk
     uint32_t batch = (uint32_t)((1ull << 30) / ((uint64_t)npix * 12ull));
     if (batch == 0) batch = 1;
     if (batch > nseg) batch = nseg;
-    int rc = scene->partial.ensure((size_t)batch * npix * 12);
+    int rc = ws.partial.ensure((size_t)batch * npix * 12);
     if (rc) return rc;
 
     RenderParams P{};
@@ -1116,7 +1171,7 @@ int enqueue_accumulate(RtScene* scene, const RtSettings* st, const RtRenderChunk
     P.seed = seed; P.sample_first = sample_first; P.sample_count = sample_count;
     P.tiles_x = (ch->width + 7) / 8;
     P.pix_slots = P.tiles_x * ((ch->height + 7) / 8) * 64;
-    P.partial = (float*)scene->partial.p;
+    P.partial = (float*)ws.partial.p;
     P.counters = counters_dev;
     P.strip_h = il.strip_h; P.strip_period_rows = il.period_rows; P.strip_first_row = il.first_row;
     {
@@ -1129,10 +1184,12 @@ int enqueue_accumulate(RtScene* scene, const RtSettings* st, const RtRenderChunk
         const uint64_t items = (uint64_t)P.pix_slots * bn;
         uint64_t blocks = (items + RT_BLOCK - 1) / RT_BLOCK;
         if (blocks > (uint64_t)scene->grid_blocks) blocks = scene->grid_blocks;
-        P.block_counter = (uint32_t*)((char*)scene->ctrl.p + 64);
+        P.block_counter = (uint32_t*)((char*)ws.ctrl.p + 64);
         HIP_TRY(hipMemsetAsync(P.block_counter, 0, sizeof(uint32_t), stream));
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
-        if (scene->profiling) { HIP_TRY(hipEventCreate(&ev0)); HIP_TRY(hipEventCreate(&ev1)); HIP_TRY(hipEventRecord(ev0, stream)); }
+        bool profiling;
+        { std::lock_guard<std::mutex> pg(scene->profile_lock); profiling = scene->profiling; }
+        if (profiling) { HIP_TRY(hipEventCreate(&ev0)); HIP_TRY(hipEventCreate(&ev1)); HIP_TRY(hipEventRecord(ev0, stream)); }
 #ifdef RT_PHASE_STATS
         static unsigned long long* phase_dev = nullptr;
         if (!phase_dev) HIP_TRY(hipMalloc((void**)&phase_dev, PH_COUNT * 16));
@@ -1151,8 +1208,12 @@ int enqueue_accumulate(RtScene* scene, const RtSettings* st, const RtRenderChunk
                 fprintf(stderr, "phase %-18s lanes %14llu passes %12llu util %.3f\n", names[k], h[2 * k], h[2 * k + 1], h[2 * k + 1] ? (double)h[2 * k] / (64.0 * (double)h[2 * k + 1]) : 0.0);
         }
 #endif
-        if (scene->profiling) { HIP_TRY(hipEventRecord(ev1, stream)); scene->profile_events.emplace_back(ev0, ev1); }
-        hipLaunchKernelGGL(fold_kernel, dim3((npix + 255) / 256), dim3(256), 0, stream, (const float*)scene->partial.p, bn, npix, acc, acc_pitch,
+        if (profiling) {
+            HIP_TRY(hipEventRecord(ev1, stream));
+            std::lock_guard<std::mutex> pg(scene->profile_lock);
+            scene->profile_events.emplace_back(ev0, ev1);
+        }
+        hipLaunchKernelGGL(fold_kernel, dim3((npix + 255) / 256), dim3(256), 0, stream, (const float*)ws.partial.p, bn, npix, acc, acc_pitch,
                            ch->width, acc_x, acc_y, (init_zero && b0 == 0) ? 1 : 0);
         HIP_TRY(hipGetLastError());
     }
@@ -1198,7 +1259,6 @@ RtScene* rt_scene_create(const RtSceneDesc* desc, int device) {
         upload(s, flat.textures, &s->view.textures) || upload(s, flat.tex_set_entries, &s->view.tex_set_entries) ||
         upload(s, flat.texels, &s->view.texels) || upload(s, flat.lights, &s->view.lights))
         return fail();
-    if (hipStreamCreate(&s->stream) != hipSuccess) { set_error(RT_E_HIP, "hipStreamCreate failed"); return fail(); }
     // launch shape: a resident grid (persistent lanes stride over the work items)
     s->lds_bytes = (size_t)s->view.stack_entries * RT_BLOCK * sizeof(uint32_t);
     if (s->lds_bytes > 64 * 1024) { set_error(RT_E_DEPTH, "BVH too deep for the LDS traversal stack (more than 64 levels)"); return fail(); }
@@ -1207,7 +1267,7 @@ RtScene* rt_scene_create(const RtSceneDesc* desc, int device) {
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_kernel, RT_BLOCK, s->lds_bytes) != hipSuccess || per_cu < 1) per_cu = 1;
     s->grid_blocks = prop.multiProcessorCount * per_cu;
-    if (s->ctrl.ensure(256)) return fail();
+    if (s->shared.init(false)) return fail();
     return s;
 }
 
@@ -1215,24 +1275,25 @@ void rt_scene_destroy(RtScene* s) {
     if (!s) return;
     if (s->device == RT_DEVICE_HOST_ONLY) { delete s; return; }
     (void)hipSetDevice(s->device);
-    if (s->stream) { (void)hipStreamSynchronize(s->stream); (void)hipStreamDestroy(s->stream); }
+    (void)hipDeviceSynchronize();
+    for (auto& w : s->pool) w->release();
+    s->shared.release();
     for (void* p : s->allocations) (void)hipFree(p);
-    s->partial.release(); s->accum.release(); s->out_rgb.release(); s->out_rgba.release(); s->ctrl.release(); s->prim.release();
     delete s;
 }
 
-// body of rt_render_chunk_device; the caller holds scene->lock
-static int render_chunk_device_locked(RtScene* scene, const RtSettings* st, const RtRenderChunk* ch, uint64_t seed, void* rgb_dev, void* rgba_dev,
+// body of rt_render_chunk_device on workspace `ws` (the shared one: the caller holds scene->lock)
+static int render_chunk_device_on(RtScene* scene, Workspace& ws, const RtSettings* st, const RtRenderChunk* ch, uint64_t seed, void* rgb_dev, void* rgba_dev,
                                       uint32_t pitch_pixels, uint32_t out_x, uint32_t out_y, void* counters_dev, hipStream_t sm) {
     if ((uint64_t)out_x + ch->width > pitch_pixels) return set_error(RT_E_INVALID, "output pitch too small for the chunk");
     HIP_TRY(hipSetDevice(scene->device));
     const uint32_t npix = ch->width * ch->height;
-    int rc = scene->accum.ensure((size_t)npix * 12);
+    int rc = ws.accum.ensure((size_t)npix * 12);
     if (rc) return rc;
-    rc = enqueue_accumulate(scene, st, ch, seed, 0, st->samples_per_pixel, (float*)scene->accum.p, ch->width, 0, 0, true,
+    rc = enqueue_accumulate(scene, ws, st, ch, seed, 0, st->samples_per_pixel, (float*)ws.accum.p, ch->width, 0, 0, true,
                             (unsigned long long*)counters_dev, sm);
     if (rc) return rc;
-    hipLaunchKernelGGL(finish_kernel, dim3((npix + 255) / 256), dim3(256), 0, sm, (const float*)scene->accum.p, ch->width, 0u, 0u, ch->width, npix,
+    hipLaunchKernelGGL(finish_kernel, dim3((npix + 255) / 256), dim3(256), 0, sm, (const float*)ws.accum.p, ch->width, 0u, 0u, ch->width, npix,
                        (float)st->samples_per_pixel, (float*)rgb_dev, (uint8_t*)rgba_dev, pitch_pixels, out_x, out_y);
     HIP_TRY(hipGetLastError());
     return RT_OK;
@@ -1243,7 +1304,7 @@ int rt_render_chunk_device(RtScene* scene, const RtSettings* st, const RtRenderC
     int rc = validate_call(scene, st, ch);
     if (rc) return rc;
     std::lock_guard<std::mutex> g(scene->lock);
-    return render_chunk_device_locked(scene, st, ch, seed, rgb_dev, rgba_dev, pitch_pixels, out_x, out_y, counters_dev, (hipStream_t)stream);
+    return render_chunk_device_on(scene, scene->shared, st, ch, seed, rgb_dev, rgba_dev, pitch_pixels, out_x, out_y, counters_dev, (hipStream_t)stream);
 }
 
 int rt_render_chunk(RtScene* scene, const RtSettings* st, const RtRenderChunk* ch, uint64_t seed, float* rgb_out, uint8_t* rgba_out,
@@ -1251,17 +1312,19 @@ int rt_render_chunk(RtScene* scene, const RtSettings* st, const RtRenderChunk* c
     int rc = validate_call(scene, st, ch);
     if (rc) return rc;
     const size_t npix = (size_t)ch->width * ch->height;
-    std::lock_guard<std::mutex> g(scene->lock);
     HIP_TRY(hipSetDevice(scene->device));
-    if ((rc = scene->out_rgb.ensure(npix * 12)) || (rc = scene->out_rgba.ensure(npix * 4))) return rc;
-    HIP_TRY(hipMemsetAsync(scene->ctrl.p, 0, sizeof(RtRayCounters), scene->stream));
-    rc = render_chunk_device_locked(scene, st, ch, seed, scene->out_rgb.p, scene->out_rgba.p, ch->width, 0, 0, scene->ctrl.p, scene->stream);
-    if (rc) return rc;
+    WorkspaceLease lease(scene);          // concurrent callers get a workspace and a stream each
+    if (lease.rc) return lease.rc;
+    Workspace& ws = *lease.ws;
+    if ((rc = ws.out_rgb.ensure(npix * 12)) || (rc = ws.out_rgba.ensure(npix * 4))) return rc;
+    HIP_TRY(hipMemsetAsync(ws.ctrl.p, 0, sizeof(RtRayCounters), ws.stream));
+    rc = render_chunk_device_on(scene, ws, st, ch, seed, ws.out_rgb.p, ws.out_rgba.p, ch->width, 0, 0, ws.ctrl.p, ws.stream);
+    if (rc) { (void)hipStreamSynchronize(ws.stream); return rc; }
     RtRayCounters c{};
-    if (rgb_out) HIP_TRY(hipMemcpyAsync(rgb_out, scene->out_rgb.p, npix * 12, hipMemcpyDeviceToHost, scene->stream));
-    if (rgba_out) HIP_TRY(hipMemcpyAsync(rgba_out, scene->out_rgba.p, npix * 4, hipMemcpyDeviceToHost, scene->stream));
-    HIP_TRY(hipMemcpyAsync(&c, scene->ctrl.p, sizeof(c), hipMemcpyDeviceToHost, scene->stream));
-    HIP_TRY(hipStreamSynchronize(scene->stream));
+    if (rgb_out) HIP_TRY(hipMemcpyAsync(rgb_out, ws.out_rgb.p, npix * 12, hipMemcpyDeviceToHost, ws.stream));
+    if (rgba_out) HIP_TRY(hipMemcpyAsync(rgba_out, ws.out_rgba.p, npix * 4, hipMemcpyDeviceToHost, ws.stream));
+    HIP_TRY(hipMemcpyAsync(&c, ws.ctrl.p, sizeof(c), hipMemcpyDeviceToHost, ws.stream));
+    HIP_TRY(hipStreamSynchronize(ws.stream));
     if (counters) { counters->primary += c.primary; counters->secondary += c.secondary; counters->shadow += c.shadow; counters->samples += c.samples; }
     return RT_OK;
 }
@@ -1290,12 +1353,13 @@ int rt_render_strips_device(RtScene* scene, const RtSettings* st, uint32_t strip
     HIP_TRY(hipSetDevice(scene->device));
     hipStream_t sm = (hipStream_t)stream;
     const uint32_t npix = local.width * local.height;
-    if ((rc = scene->accum.ensure((size_t)npix * 12))) return rc;
+    Workspace& ws = scene->shared;
+    if ((rc = ws.accum.ensure((size_t)npix * 12))) return rc;
     Interleave il; il.strip_h = strip_height; il.period_rows = strip_period * strip_height; il.first_row = strip_first * strip_height;
-    rc = enqueue_accumulate(scene, st, &local, seed, 0, st->samples_per_pixel, (float*)scene->accum.p, local.width, 0, 0, true,
+    rc = enqueue_accumulate(scene, ws, st, &local, seed, 0, st->samples_per_pixel, (float*)ws.accum.p, local.width, 0, 0, true,
                             (unsigned long long*)counters_dev, sm, il);
     if (rc) return rc;
-    hipLaunchKernelGGL(finish_kernel, dim3((npix + 255) / 256), dim3(256), 0, sm, (const float*)scene->accum.p, local.width, 0u, 0u, local.width, npix,
+    hipLaunchKernelGGL(finish_kernel, dim3((npix + 255) / 256), dim3(256), 0, sm, (const float*)ws.accum.p, local.width, 0u, 0u, local.width, npix,
                        (float)st->samples_per_pixel, (float*)rgb_dev, (uint8_t*)rgba_dev, local.width, 0u, 0u);
     HIP_TRY(hipGetLastError());
     return RT_OK;
@@ -1308,7 +1372,7 @@ int rt_accumulate_chunk_device(RtScene* scene, const RtSettings* st, const RtRen
     if (!accum_dev) return set_error(RT_E_INVALID, "null accumulator");
     std::lock_guard<std::mutex> g(scene->lock);
     HIP_TRY(hipSetDevice(scene->device));
-    return enqueue_accumulate(scene, st, ch, seed, sample_first, sample_count, (float*)accum_dev, st->width, ch->left, ch->top, false,
+    return enqueue_accumulate(scene, scene->shared, st, ch, seed, sample_first, sample_count, (float*)accum_dev, st->width, ch->left, ch->top, false,
                               (unsigned long long*)counters_dev, (hipStream_t)stream);
 }
 
@@ -1326,22 +1390,24 @@ int rt_primary_hits(RtScene* scene, const RtSettings* st, const RtRenderChunk* c
                     int32_t* tri_out) {
     int rc = validate_call(scene, st, ch);
     if (rc) return rc;
-    std::lock_guard<std::mutex> g(scene->lock);
     HIP_TRY(hipSetDevice(scene->device));
+    WorkspaceLease lease(scene);
+    if (lease.rc) return lease.rc;
+    Workspace& ws = *lease.ws;
     const size_t npix = (size_t)ch->width * ch->height;
-    if ((rc = scene->prim.ensure(npix * 24))) return rc;
-    float* d_t = (float*)scene->prim.p; float* d_n = d_t + npix; int32_t* d_e = (int32_t*)(d_n + 3 * npix); int32_t* d_tri = d_e + npix;
+    if ((rc = ws.prim.ensure(npix * 24))) return rc;
+    float* d_t = (float*)ws.prim.p; float* d_n = d_t + npix; int32_t* d_e = (int32_t*)(d_n + 3 * npix); int32_t* d_tri = d_e + npix;
     RenderParams P{};
     P.width = st->width; P.height = st->height; P.max_reflections = st->max_reflections; P.spp = 1;
     P.left = ch->left; P.top = ch->top; P.cw = ch->width; P.ch = ch->height;
-    hipLaunchKernelGGL(primary_kernel, dim3((uint32_t)((npix + RT_BLOCK - 1) / RT_BLOCK)), dim3(RT_BLOCK), scene->lds_bytes, scene->stream,
+    hipLaunchKernelGGL(primary_kernel, dim3((uint32_t)((npix + RT_BLOCK - 1) / RT_BLOCK)), dim3(RT_BLOCK), scene->lds_bytes, ws.stream,
                        scene->view, P, d_t, d_n, d_e, d_tri);
     HIP_TRY(hipGetLastError());
-    if (t_out) HIP_TRY(hipMemcpyAsync(t_out, d_t, npix * 4, hipMemcpyDeviceToHost, scene->stream));
-    if (normal_out) HIP_TRY(hipMemcpyAsync(normal_out, d_n, npix * 12, hipMemcpyDeviceToHost, scene->stream));
-    if (entity_out) HIP_TRY(hipMemcpyAsync(entity_out, d_e, npix * 4, hipMemcpyDeviceToHost, scene->stream));
-    if (tri_out) HIP_TRY(hipMemcpyAsync(tri_out, d_tri, npix * 4, hipMemcpyDeviceToHost, scene->stream));
-    HIP_TRY(hipStreamSynchronize(scene->stream));
+    if (t_out) HIP_TRY(hipMemcpyAsync(t_out, d_t, npix * 4, hipMemcpyDeviceToHost, ws.stream));
+    if (normal_out) HIP_TRY(hipMemcpyAsync(normal_out, d_n, npix * 12, hipMemcpyDeviceToHost, ws.stream));
+    if (entity_out) HIP_TRY(hipMemcpyAsync(entity_out, d_e, npix * 4, hipMemcpyDeviceToHost, ws.stream));
+    if (tri_out) HIP_TRY(hipMemcpyAsync(tri_out, d_tri, npix * 4, hipMemcpyDeviceToHost, ws.stream));
+    HIP_TRY(hipStreamSynchronize(ws.stream));
     return RT_OK;
 }
 
@@ -1361,14 +1427,14 @@ int rt_scene_info(const RtScene* scene, RtSceneInfo* out) {
 
 int rt_scene_profile_enable(RtScene* scene, int enable) {
     if (!scene) return set_error(RT_E_INVALID, "null scene");
-    std::lock_guard<std::mutex> g(scene->lock);
+    std::lock_guard<std::mutex> g(scene->profile_lock);
     scene->profiling = enable != 0;
     return RT_OK;
 }
 
 int rt_scene_profile_read(RtScene* scene, double* kernel_ms_total, uint64_t* launches) {
     if (!scene) return set_error(RT_E_INVALID, "null scene");
-    std::lock_guard<std::mutex> g(scene->lock);
+    std::lock_guard<std::mutex> g(scene->profile_lock);
     if (scene->device != RT_DEVICE_HOST_ONLY) HIP_TRY(hipSetDevice(scene->device));
     double total = 0.0;
     for (auto& ev : scene->profile_events) {

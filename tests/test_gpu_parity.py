@@ -133,6 +133,26 @@ def test_image_independent_of_chunking():
     assert not np.array_equal(whole, other)
 
 
+def test_concurrent_host_threads_render_the_same_frame():
+    """rt_render_chunk from several host threads at once (the reference's worker threads, src/render.rs:186-224):
+    each call borrows its own workspace and stream; the frame is bit-identical to the one-call frame."""
+    from concurrent.futures import ThreadPoolExecutor
+    w, h = 200, 120
+    b, scene, oracle = make("Mesh", w, h)
+    st = RenderSettings(w, h, 6, 4)
+    whole, whole8, cn = scene.render_chunk(st, RenderChunk(0, 0, w, h), seed=11)
+    chunks = create_render_chunks((w, h), (6, 5))
+    for threads in (2, 12):                       # 12 > the pool of 8 workspaces: callers wait for a free one
+        with ThreadPoolExecutor(threads) as ex:
+            parts = list(ex.map(lambda c: scene.render_chunk(st, c, seed=11), chunks))
+        frame, frame8, rays = np.zeros_like(whole), np.zeros_like(whole8), 0
+        for c, (rgb, rgba, k) in zip(chunks, parts):
+            frame[c.top:c.top + c.height, c.left:c.left + c.width] = rgb
+            frame8[c.top:c.top + c.height, c.left:c.left + c.width] = rgba
+            rays += k.rays
+        assert np.array_equal(frame, whole) and np.array_equal(frame8, whole8) and rays == cn.rays
+
+
 def test_interleaved_strips_equal_full_frame():
     """rt_render_strips_device (what each of N GPUs runs) gives exactly the rows of the
     single-GPU frame; here the N ranks are emulated one after the other on one GPU."""
