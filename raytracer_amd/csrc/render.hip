@@ -28,6 +28,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <condition_variable>
 #include <memory>
 #include <mutex>
@@ -517,9 +518,10 @@ struct RenderParams {
     uint32_t left, top, cw, ch;                     // RenderChunk
     uint64_t seed;
     uint32_t sample_first, sample_count;            // absolute sample index range to render
-    uint32_t seg_first, seg_count;                  // segments covered by this launch
+    uint32_t unit_len;                              // samples per work item: RT_SAMPLE_SEGMENT (coarse) or 1 (fine)
+    uint32_t unit_first, unit_count;                // units (absolute index = sample / unit_len) covered by this launch
     uint32_t tiles_x, pix_slots;                    // 8x8 tiling of the chunk; pix_slots = tiles*64
-    float* partial;                                 // [seg_count][cw*ch][3] segment sums
+    float* partial;                                 // [unit_count][cw*ch][3] sums of the clamped samples of each unit
     unsigned long long* counters;                   // RtRayCounters on the device (nullable)
     uint32_t refill_lanes;                          // idle lanes that end a traversal burst
     uint32_t* block_counter;                        // next unclaimed block of 64 work items (zeroed per launch)
@@ -568,7 +570,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
     // to the next block together, so the rays of a wave stay spatially coherent.
     // Blocks are claimed dynamically (one atomic per wave and block), so waves that
     // drew cheap tiles simply take more of them.
-    const uint32_t total_items = P.pix_slots * P.seg_count;
+    const uint32_t total_items = P.pix_slots * P.unit_count;
     const uint32_t lane = threadIdx.x & 63u;
 
     uint32_t n_primary = 0, n_secondary = 0, n_shadow = 0, n_samples = 0;
@@ -612,19 +614,18 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                 const uint32_t item = blk * 64u + lane;
                 if (blk >= (total_items >> 6)) state = FINISHED;      // pix_slots is a multiple of 64
                 else {
-                    const uint32_t seg_local = item / P.pix_slots, q = item % P.pix_slots;
+                    const uint32_t unit_local = item / P.pix_slots, q = item % P.pix_slots;
                     const uint32_t tile = q >> 6, within = q & 63u;
                     const uint32_t x = (tile % P.tiles_x) * 8u + (within & 7u), y = (tile / P.tiles_x) * 8u + (within >> 3);
                     if (x < P.cw && y < P.ch) {       // lanes off the chunk's edge sit this block out
-                        const uint32_t seg = P.seg_first + seg_local;
-                        const uint32_t sa = seg * RT_SAMPLE_SEGMENT, sb = sa + RT_SAMPLE_SEGMENT;
+                        const uint32_t sa = (P.unit_first + unit_local) * P.unit_len, sb = sa + P.unit_len;
                         const uint32_t r_end = P.sample_first + P.sample_count;
                         s = sa > P.sample_first ? sa : P.sample_first;
                         s_end = sb < r_end ? sb : r_end;
                         px = P.left + x;
                         py = P.strip_h ? P.strip_first_row + (y / P.strip_h) * P.strip_period_rows + (y % P.strip_h) : P.top + y;
                         pixel_uv(P, px, py, pu, pv);
-                        out_slot = seg_local * (P.cw * P.ch) + y * P.cw + x;
+                        out_slot = unit_local * (P.cw * P.ch) + y * P.cw + x;
                         seg_sum = f3(0.0f, 0.0f, 0.0f);
                         state = NEED_SAMPLE;
                     }
@@ -969,17 +970,31 @@ render_kernel(const DevSceneView S, const RenderParams P) {
 }
 
 // Folds segment sums into the accumulator in segment order:
-// acc = (first ? 0 : acc) + seg0 + seg1 + ...   (sequential, implementation.rs:656)
-__global__ void fold_kernel(const float* partial, uint32_t seg_count, uint32_t npix, float* acc, uint32_t acc_pitch, uint32_t cw,
-                            uint32_t acc_x, uint32_t acc_y, int init_zero) {
+// acc = (first ? 0 : acc) + seg0 + seg1 + ...   (sequential, implementation.rs:656).
+// With one-sample units the segment sums ((0 + c0) + c1) + ... are formed here, with the very
+// additions the render kernel performs for a whole-segment unit: both splits give the same bits.
+__global__ void fold_kernel(const float* partial, uint32_t unit_count, uint32_t unit_first, uint32_t unit_len, uint32_t npix, float* acc,
+                            uint32_t acc_pitch, uint32_t cw, uint32_t acc_x, uint32_t acc_y, int init_zero) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= npix) return;
     const uint32_t x = i % cw, y = i / cw;
     float* a = acc + ((uint64_t)(acc_y + y) * acc_pitch + acc_x + x) * 3;
     float r = init_zero ? 0.0f : a[0], g = init_zero ? 0.0f : a[1], b = init_zero ? 0.0f : a[2];
-    for (uint32_t s = 0; s < seg_count; s++) {
-        const float* p = partial + ((uint64_t)s * npix + i) * 3;
-        r = r + p[0]; g = g + p[1]; b = b + p[2];
+    if (unit_len == RT_SAMPLE_SEGMENT) {             // units are whole segment sums
+        for (uint32_t u = 0; u < unit_count; u++) {
+            const float* p = partial + ((uint64_t)u * npix + i) * 3;
+            r = r + p[0]; g = g + p[1]; b = b + p[2];
+        }
+    } else {                                         // units are single samples: form each segment sum first, in sample order
+        float sr = 0.0f, sg = 0.0f, sb = 0.0f;
+        for (uint32_t u = 0; u < unit_count; u++) {
+            const float* p = partial + ((uint64_t)u * npix + i) * 3;
+            sr = sr + p[0]; sg = sg + p[1]; sb = sb + p[2];
+            if (((unit_first + u + 1u) % RT_SAMPLE_SEGMENT) == 0u || u + 1u == unit_count) {
+                r = r + sr; g = g + sg; b = b + sb;
+                sr = 0.0f; sg = 0.0f; sb = 0.0f;
+            }
+        }
     }
     a[0] = r; a[1] = g; a[2] = b;
 }
@@ -1086,6 +1101,7 @@ struct RtScene {
     std::condition_variable pool_cv;
     std::vector<std::unique_ptr<Workspace>> pool;
     std::vector<Workspace*> pool_free;
+    std::atomic<int> host_calls_in_flight{0};
     int grid_blocks = 0;
     size_t lds_bytes = 0;
     std::mutex profile_lock;
@@ -1099,6 +1115,7 @@ namespace {
 struct WorkspaceLease {
     RtScene* scene; Workspace* ws = nullptr; int rc = RT_OK;
     explicit WorkspaceLease(RtScene* s) : scene(s) {
+        s->host_calls_in_flight.fetch_add(1);
         std::unique_lock<std::mutex> g(s->pool_lock);
         for (;;) {
             if (!s->pool_free.empty()) { ws = s->pool_free.back(); s->pool_free.pop_back(); return; }
@@ -1113,6 +1130,7 @@ struct WorkspaceLease {
         }
     }
     ~WorkspaceLease() {
+        scene->host_calls_in_flight.fetch_sub(1);
         if (!ws) return;
         { std::lock_guard<std::mutex> g(scene->pool_lock); scene->pool_free.push_back(ws); }
         scene->pool_cv.notify_one();
@@ -1158,19 +1176,33 @@ int enqueue_accumulate(RtScene* scene, Workspace& ws, const RtSettings* st, cons
     const uint32_t seg_lo = sample_first / RT_SAMPLE_SEGMENT;
     const uint32_t seg_hi = (sample_first + sample_count - 1) / RT_SAMPLE_SEGMENT;     // inclusive
     const uint32_t nseg = seg_hi - seg_lo + 1;
-    // segment sums of one launch: keep the scratch below ~1 GiB
-    uint32_t batch = (uint32_t)((1ull << 30) / ((uint64_t)npix * 12ull));
+    const uint32_t tiles_x = (ch->width + 7) / 8;
+    const uint32_t pix_slots = tiles_x * ((ch->height + 7) / 8) * 64;
+    // Work split.  Coarse: one work item = one pixel x one whole segment (best lane utilisation:
+    // a wave waits for its slowest lane once per 8 samples).  Fine: one item = one sample, for
+    // launches that would leave the GPU under-filled or be dominated by their slowest wave
+    // (small frames, small chunks).  Same bits either way (see fold_kernel).
+    // Measured (weekend): a full GPU runs the fine split 2x slower (49 -> 98 ms per 1080p frame), an
+    // under-filled one up to 4x faster (400x225x16: 2.48 -> 0.63 ms); so: fine only when the coarse
+    // blocks would not even occupy the resident waves and no other host call is rendering on this
+    // scene at the same time (concurrent chunk calls fill the GPU together).
+    const uint64_t coarse_blocks = (uint64_t)(pix_slots / 64) * nseg;
+    bool fine = coarse_blocks < (uint64_t)scene->grid_blocks * (RT_BLOCK / 64) && scene->host_calls_in_flight.load() <= 1;
+    if (const char* e = getenv("RT_FINE_SPLIT")) fine = atoi(e) != 0;                    // experiments / tests: force either split
+    const uint32_t unit_len = fine ? 1u : RT_SAMPLE_SEGMENT;
+    // segments per launch: keep the scratch below ~1 GiB
+    const uint32_t units_per_seg = RT_SAMPLE_SEGMENT / unit_len;
+    uint32_t batch = (uint32_t)((1ull << 30) / ((uint64_t)npix * 12ull * units_per_seg));
     if (batch == 0) batch = 1;
     if (batch > nseg) batch = nseg;
-    int rc = ws.partial.ensure((size_t)batch * npix * 12);
+    int rc = ws.partial.ensure((size_t)batch * units_per_seg * npix * 12);
     if (rc) return rc;
 
     RenderParams P{};
     P.width = st->width; P.height = st->height; P.max_reflections = st->max_reflections; P.spp = st->samples_per_pixel;
     P.left = ch->left; P.top = ch->top; P.cw = ch->width; P.ch = ch->height;
     P.seed = seed; P.sample_first = sample_first; P.sample_count = sample_count;
-    P.tiles_x = (ch->width + 7) / 8;
-    P.pix_slots = P.tiles_x * ((ch->height + 7) / 8) * 64;
+    P.tiles_x = tiles_x; P.pix_slots = pix_slots; P.unit_len = unit_len;
     P.partial = (float*)ws.partial.p;
     P.counters = counters_dev;
     P.strip_h = il.strip_h; P.strip_period_rows = il.period_rows; P.strip_first_row = il.first_row;
@@ -1180,8 +1212,12 @@ int enqueue_accumulate(RtScene* scene, Workspace& ws, const RtSettings* st, cons
     }
     for (uint32_t b0 = 0; b0 < nseg; b0 += batch) {
         const uint32_t bn = (nseg - b0 < batch) ? nseg - b0 : batch;
-        P.seg_first = seg_lo + b0; P.seg_count = bn;
-        const uint64_t items = (uint64_t)P.pix_slots * bn;
+        // the units of segments [seg_lo + b0, seg_lo + b0 + bn) that hold samples of the range
+        const uint32_t s_lo = (seg_lo + b0) * RT_SAMPLE_SEGMENT > sample_first ? (seg_lo + b0) * RT_SAMPLE_SEGMENT : sample_first;
+        const uint32_t s_hi = (seg_lo + b0 + bn) * RT_SAMPLE_SEGMENT < sample_first + sample_count ? (seg_lo + b0 + bn) * RT_SAMPLE_SEGMENT
+                                                                                                    : sample_first + sample_count;     // exclusive
+        P.unit_first = s_lo / unit_len; P.unit_count = (s_hi - 1) / unit_len - P.unit_first + 1;
+        const uint64_t items = (uint64_t)P.pix_slots * P.unit_count;
         uint64_t blocks = (items + RT_BLOCK - 1) / RT_BLOCK;
         if (blocks > (uint64_t)scene->grid_blocks) blocks = scene->grid_blocks;
         P.block_counter = (uint32_t*)((char*)ws.ctrl.p + 64);
@@ -1213,7 +1249,7 @@ int enqueue_accumulate(RtScene* scene, Workspace& ws, const RtSettings* st, cons
             std::lock_guard<std::mutex> pg(scene->profile_lock);
             scene->profile_events.emplace_back(ev0, ev1);
         }
-        hipLaunchKernelGGL(fold_kernel, dim3((npix + 255) / 256), dim3(256), 0, stream, (const float*)ws.partial.p, bn, npix, acc, acc_pitch,
+        hipLaunchKernelGGL(fold_kernel, dim3((npix + 255) / 256), dim3(256), 0, stream, (const float*)ws.partial.p, P.unit_count, P.unit_first, unit_len, npix, acc, acc_pitch,
                            ch->width, acc_x, acc_y, (init_zero && b0 == 0) ? 1 : 0);
         HIP_TRY(hipGetLastError());
     }
