@@ -84,6 +84,7 @@ struct DevSceneView {
     uint32_t tlas_root_ref;
     uint32_t stack_entries;       // per-lane traversal stack depth the trees need
     uint32_t shadow_any_hit;      // no dielectric material in the scene: any occluder ends a shadow ray
+    uint32_t recursive_materials; // some material casts reflection / refraction rays
     const DevNode* nodes;         // TLAS nodes first, then every BLAS
     const DevEntity* entities;    // TLAS leaf order
     const Word4* xforms;
