@@ -85,6 +85,7 @@ struct DevSceneView {
     uint32_t stack_entries;       // per-lane traversal stack depth the trees need
     uint32_t shadow_any_hit;      // no dielectric material in the scene: any occluder ends a shadow ray
     uint32_t recursive_materials; // some material casts reflection / refraction rays
+    uint32_t mesh_entities;       // some entity is a mesh instance (the walk enters BLASes)
     const DevNode* nodes;         // TLAS nodes first, then every BLAS
     const DevEntity* entities;    // TLAS leaf order
     const Word4* xforms;

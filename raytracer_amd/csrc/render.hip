@@ -803,6 +803,10 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                 o = shadow ? hp : ro;
                 d = shadow ? -ldir : rd;
                 inv = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                if (S.mesh_entities) {      // read back when the walk leaves an instance (three divisions saved per exit)
+                    stack[stack_cap * RT_BLOCK] = __float_as_uint(inv.x); stack[(stack_cap + 1u) * RT_BLOCK] = __float_as_uint(inv.y);
+                    stack[(stack_cap + 2u) * RT_BLOCK] = __float_as_uint(inv.z);
+                }
                 t_min = shadow ? closest : RT_BIAS; t_max = shadow ? l_t : RT_F32_MAX;
                 best.t = t_max; best.ent = RT_NONE; best.tri = RT_NONE; best.erank = 0; best_t = t_max;
                 sp = 0; inst_sp = RT_NONE; nodes = S.nodes;
@@ -822,7 +826,9 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                 inst_sp = RT_NONE; nodes = S.nodes;
                 const bool shadow = state == SHADOW;
                 o = shadow ? hp : ro; d = shadow ? -ldir : rd;
-                inv = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                // the world-space reciprocals were parked in this lane's LDS column at the start of the ray
+                inv = f3(__uint_as_float(stack[stack_cap * RT_BLOCK]), __uint_as_float(stack[(stack_cap + 1u) * RT_BLOCK]),
+                         __uint_as_float(stack[(stack_cap + 2u) * RT_BLOCK]));
             }
             if (sp == 0) return RT_NONE;
             return stack[(--sp) * RT_BLOCK];
@@ -1386,7 +1392,7 @@ RtScene* rt_scene_create(const RtSceneDesc* desc, int device) {
         upload(s, flat.texels, &s->view.texels) || upload(s, flat.lights, &s->view.lights))
         return fail();
     // launch shape: a resident grid (persistent lanes stride over the work items)
-    s->lds_bytes = (size_t)s->view.stack_entries * RT_BLOCK * sizeof(uint32_t);
+    s->lds_bytes = ((size_t)s->view.stack_entries + 3) * RT_BLOCK * sizeof(uint32_t);      // + 3 rows: parked world-space 1/d
     if (s->lds_bytes > 64 * 1024) { set_error(RT_E_DEPTH, "BVH too deep for the LDS traversal stack (more than 64 levels)"); return fail(); }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { set_error(RT_E_HIP, "hipGetDeviceProperties failed"); return fail(); }
