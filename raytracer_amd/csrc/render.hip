@@ -523,7 +523,7 @@ struct RenderParams {
     uint32_t unit_len;                              // samples per work item: RT_SAMPLE_SEGMENT (coarse) or 1 (fine)
     uint32_t unit_first, unit_count;                // units (absolute index = sample / unit_len) covered by this launch
     uint32_t tiles_x, pix_slots;                    // 8x8 tiling of the chunk; pix_slots = tiles*64
-    float* partial;                                 // [unit_count][cw*ch][3] sums of the clamped samples of each unit
+    float* partial;                                 // [unit_count][tile][64][3] sums of the clamped samples of each unit (8x8 tiles of the chunk)
     unsigned long long* counters;                   // RtRayCounters on the device (nullable)
     uint32_t refill_lanes;                          // idle lanes that end a traversal burst
     uint32_t* block_counter;                        // next unclaimed block of 64 work items (zeroed per launch)
@@ -635,7 +635,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                         px = P.left + x;
                         py = P.strip_h ? P.strip_first_row + (y / P.strip_h) * P.strip_period_rows + (y % P.strip_h) : P.top + y;
                         pixel_uv(P, px, py, pu, pv);
-                        out_slot = unit_local * (P.cw * P.ch) + y * P.cw + x;
+                        out_slot = (unit_local * n_tiles + tile) * 64u + within;      // one block = 768 contiguous bytes
                         seg_sum = f3(0.0f, 0.0f, 0.0f);
                         state = NEED_SAMPLE;
                     }
@@ -990,21 +990,22 @@ render_kernel(const DevSceneView S, const RenderParams P) {
 // With one-sample units the segment sums ((0 + c0) + c1) + ... are formed here, with the very
 // additions the render kernel performs for a whole-segment unit: both splits give the same bits.
 __global__ void fold_kernel(const float* partial, uint32_t unit_count, uint32_t unit_first, uint32_t unit_len, uint32_t npix, float* acc,
-                            uint32_t acc_pitch, uint32_t cw, uint32_t acc_x, uint32_t acc_y, int init_zero) {
+                            uint32_t acc_pitch, uint32_t cw, uint32_t acc_x, uint32_t acc_y, int init_zero, uint32_t tiles_x, uint32_t pix_slots) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= npix) return;
     const uint32_t x = i % cw, y = i / cw;
+    const uint32_t slot = ((y >> 3) * tiles_x + (x >> 3)) * 64u + (y & 7u) * 8u + (x & 7u);      // the render kernel's tile layout
     float* a = acc + ((uint64_t)(acc_y + y) * acc_pitch + acc_x + x) * 3;
     float r = init_zero ? 0.0f : a[0], g = init_zero ? 0.0f : a[1], b = init_zero ? 0.0f : a[2];
     if (unit_len == RT_SAMPLE_SEGMENT) {             // units are whole segment sums
         for (uint32_t u = 0; u < unit_count; u++) {
-            const float* p = partial + ((uint64_t)u * npix + i) * 3;
+            const float* p = partial + ((uint64_t)u * pix_slots + slot) * 3;
             r = r + p[0]; g = g + p[1]; b = b + p[2];
         }
     } else {                                         // units are single samples: form each segment sum first, in sample order
         float sr = 0.0f, sg = 0.0f, sb = 0.0f;
         for (uint32_t u = 0; u < unit_count; u++) {
-            const float* p = partial + ((uint64_t)u * npix + i) * 3;
+            const float* p = partial + ((uint64_t)u * pix_slots + slot) * 3;
             sr = sr + p[0]; sg = sg + p[1]; sb = sb + p[2];
             if (((unit_first + u + 1u) % RT_SAMPLE_SEGMENT) == 0u || u + 1u == unit_count) {
                 r = r + sr; g = g + sg; b = b + sb;
@@ -1275,10 +1276,10 @@ int enqueue_accumulate(RtScene* scene, Workspace& ws, const RtSettings* st, cons
     const uint32_t unit_len = fine ? 1u : RT_SAMPLE_SEGMENT;
     // segments per launch: keep the scratch below ~1 GiB
     const uint32_t units_per_seg = RT_SAMPLE_SEGMENT / unit_len;
-    uint32_t batch = (uint32_t)((1ull << 30) / ((uint64_t)npix * 12ull * units_per_seg));
+    uint32_t batch = (uint32_t)((1ull << 30) / ((uint64_t)pix_slots * 12ull * units_per_seg));
     if (batch == 0) batch = 1;
     if (batch > nseg) batch = nseg;
-    int rc = ws.partial.ensure((size_t)batch * units_per_seg * npix * 12);
+    int rc = ws.partial.ensure((size_t)batch * units_per_seg * pix_slots * 12);
     if (rc) return rc;
 
     RenderParams P{};
@@ -1346,7 +1347,7 @@ int enqueue_accumulate(RtScene* scene, Workspace& ws, const RtSettings* st, cons
             scene->profile_events.emplace_back(ev0, ev1);
         }
         hipLaunchKernelGGL(fold_kernel, dim3((npix + 255) / 256), dim3(256), 0, stream, (const float*)ws.partial.p, P.unit_count, P.unit_first, unit_len, npix, acc, acc_pitch,
-                           ch->width, acc_x, acc_y, (init_zero && b0 == 0) ? 1 : 0);
+                           ch->width, acc_x, acc_y, (init_zero && b0 == 0) ? 1 : 0, tiles_x, pix_slots);
         HIP_TRY(hipGetLastError());
     }
     return RT_OK;
