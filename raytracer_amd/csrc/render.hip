@@ -232,7 +232,7 @@ __device__ __forceinline__ void trace(const DevSceneView& S, const F3 wo, const 
             const Word4* n = nodes[cur].w;
             const Word4 a = ldw(n), b = ldw(n + 1), c = ldw(n + 2), r = ldw(n + 3);
             float el, er; bool hl, hr;
-            slab2(a, b, c, o, inv, t_min, best_t, hl, hr, el, er);
+            slab2(a, b, c, o, inv, t_min, (S.loose_boxes && inst_sp == RT_NONE) ? t_max : best_t, hl, hr, el, er);
             if (hl && hr) {
                 const bool left_first = el <= er;
                 const uint32_t far_ref = left_first ? r.u[1] : r.u[0];
@@ -318,7 +318,7 @@ __device__ __forceinline__ void trace(const DevSceneView& S, const F3 wo, const 
                 const Word4 m0 = ldw(mw), m1 = ldw(mw + 1), m2 = ldw(mw + 2);
                 const F3 einv = f3(1.0f / ed.x, 1.0f / ed.y, 1.0f / ed.z);
                 float e;
-                if (slab(m1.f[0], m1.f[1], m1.f[2], m1.f[3], m2.f[0], m2.f[1], eo, einv, t_min, best_t, e)) {
+                if (slab(m1.f[0], m1.f[1], m1.f[2], m1.f[3], m2.f[0], m2.f[1], eo, einv, t_min, best_t, e)) {      // entity space: exact box
                     if (k + 1 < count && sp < stack_cap)
                         stack[(sp++) * RT_BLOCK] = RT_REF_LEAF_BIT | ((count - k - 2) << RT_REF_COUNT_SHIFT) | (ei + 1);
                     inst_sp = sp;
@@ -562,6 +562,9 @@ enum { PH_NODE = 0, PH_TRI, PH_ENTITY, PH_SHADE, PH_SHADE_PATH_HIT, PH_SHADE_SHA
 #define PH(i) do { } while (0)
 #endif
 
+// LOOSE: the scene has entity boxes that do not bound their hits (device_scene.h, loose_boxes):
+// TLAS boxes are then tested against the ray's whole interval, as the reference does for every box.
+template <bool LOOSE>
 __global__ void __launch_bounds__(RT_BLOCK, RT_WAVES_PER_SIMD)
 render_kernel(const DevSceneView S, const RenderParams P) {
     extern __shared__ uint32_t lds_stack[];
@@ -843,7 +846,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                     const Word4* n = nodes[cur].w;
                     const Word4 na = ldw(n), nb = ldw(n + 1), nc = ldw(n + 2), nr = ldw(n + 3);
                     float el, er; bool hl, hr;
-                    slab2(na, nb, nc, o, inv, t_min, best_t, hl, hr, el, er);
+                    slab2(na, nb, nc, o, inv, t_min, (LOOSE && inst_sp == RT_NONE) ? t_max : best_t, hl, hr, el, er);
                     if (hl && hr) {
                         const bool left_first = el <= er;
                         const uint32_t far_ref = left_first ? nr.u[1] : nr.u[0];
@@ -1329,7 +1332,8 @@ int enqueue_accumulate(RtScene* scene, Workspace& ws, const RtSettings* st, cons
         HIP_TRY(hipMemsetAsync(phase_dev, 0, PH_COUNT * 16, stream));
         P.phase_stats = phase_dev;
 #endif
-        hipLaunchKernelGGL(render_kernel, dim3((uint32_t)blocks), dim3(RT_BLOCK), scene->lds_bytes, stream, scene->view, P);
+        if (scene->view.loose_boxes) hipLaunchKernelGGL(render_kernel<true>, dim3((uint32_t)blocks), dim3(RT_BLOCK), scene->lds_bytes, stream, scene->view, P);
+        else hipLaunchKernelGGL(render_kernel<false>, dim3((uint32_t)blocks), dim3(RT_BLOCK), scene->lds_bytes, stream, scene->view, P);
         HIP_TRY(hipGetLastError());
 #ifdef RT_PHASE_STATS
         {
@@ -1398,7 +1402,7 @@ RtScene* rt_scene_create(const RtSceneDesc* desc, int device) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { set_error(RT_E_HIP, "hipGetDeviceProperties failed"); return fail(); }
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_kernel, RT_BLOCK, s->lds_bytes) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_kernel<false>, RT_BLOCK, s->lds_bytes) != hipSuccess || per_cu < 1) per_cu = 1;
     s->grid_blocks = prop.multiProcessorCount * per_cu;
     if (s->shared.init(false)) return fail();
     return s;

@@ -379,6 +379,11 @@ int build_flat_scene(const RtSceneDesc* d, FlatScene& out, std::string& err) {
                                   fabsf(r.axis.x) <= 2.0f && fabsf(r.axis.y) <= 2.0f && fabsf(r.axis.z) <= 2.0f;
             w1.u[3] = identity ? 1u : 0u;
             out.xforms.push_back(w0); out.xforms.push_back(w1);
+            // rotate_about_axis assumes a unit axis (types.rs:190); with any other axis the map is no
+            // rotation, Entity::hit's inverse is not its inverse, and the reference's entity boxes
+            // (calculate_origin_aabb) no longer bound what Entity::hit finds -> see loose_boxes
+            const float len2 = r.axis.x * r.axis.x + r.axis.y * r.axis.y + r.axis.z * r.axis.z;
+            if (!identity && !(fabsf(len2 - 1.0f) <= 1.0e-4f)) v.loose_boxes = 1;
         }
     }
     out.info.instanced_triangle_count = inst_tris;
