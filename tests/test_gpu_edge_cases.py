@@ -143,6 +143,30 @@ def test_degenerate_geometry_does_not_disturb_the_rest():
     assert np.isfinite(rgb).all()
 
 
+def test_axis_aligned_rays_on_box_planes():
+    """Rays with exactly zero direction components whose origin lies exactly on a box plane: (plane - o) * (1/0) =
+    0 * inf = NaN, which implementation.rs:102-115's comparisons ignore; so must v_max3 / v_min3."""
+    import os
+    cam = camera_new((1.0, 0.0, 5.0), (1.0, 0.0, 0.0), 40.0, 64 / 32, 0.0, 5.0)       # u = 0.5 (column 32) and v = 0.5 (row 16): d.x == 0, d.y == 0 exactly
+    b = SceneBuilder(cam, _ffi.RT_SKY_DAY)
+    m, tx = b.add_lambertian(), b.add_color_texture((0.3, 0.6, 0.9))
+    cube, _ = b.load_obj(os.path.join(_ffi.ASSET_MESH_DIR, "simple", "cube.obj"))        # spans [-1, 1]^3: x = 1 is a face plane
+    b.add_mesh_entity(cube, m, tx)
+    b.add_mesh_entity(cube, m, tx, translations=[(2.0, 0.0, 0.0)])                        # shares that plane from the other side
+    b.add_sphere_entity(1.0, m, tx, translations=[(1.0, 2.0, 0.0)])
+    b.add_point_light((1, 4, 6), 50.0)
+    scene, oracle = both(b)
+    w, h = 64, 32
+    st, ch = RenderSettings(w, h, 3, 1), RenderChunk(0, 0, w, h)
+    t, n, e, tri = scene.primary_hits(st, ch)
+    rt, rn, re, rtri = oracle.primary_hits(st, ch)
+    assert np.array_equal(e, re) and np.array_equal(tri, rtri) and np.array_equal(t, rt) and np.array_equal(n, rn)
+    assert (re >= 0).mean() > 0.1 and (re[:, 32] >= 0).any() and (re[16, :] >= 0).any()     # the zero-component rays hit things
+    rgb, _, cn = scene.render_chunk(st, ch, seed=2)
+    ref, _, rcn = oracle.render_chunk(st, ch, ORC_RNG_COUNTER, 2, sum_segment=sample_segment())
+    assert np.abs(rgb - ref).max() < 2e-5 and cn.rays == rcn.rays.primary + rcn.rays.secondary + rcn.rays.shadow
+
+
 def test_point_cloud_large_tlas():
     # scene_point_cloud.rs: 200 000 spheres -> a deep TLAS (stack depth, tie ranks at scale)
     from raytracer_amd import CameraConfiguration
