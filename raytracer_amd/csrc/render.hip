@@ -682,7 +682,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
             } else if (state == PATH) {
                 // cast_ray_recursive, implementation.rs:566-631
                 if (rnode == 1u) n_primary++; else n_secondary++;
-                if (best.ent == RT_NONE) { sample_col = sample_col + (rw * color_sky(S, rd)); state = NEED_PATH; }
+                if (best.ent == RT_NONE) { sample_col = sample_col + (rw * color_sky(S, rd)); rnode = 0u; state = NEED_PATH; }
                 else {
                     PH(PH_SHADE_PATH_HIT);
                     HitRec hr; resolve_hit(S, ro, rd, best, hr);
@@ -726,17 +726,24 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                     wa = rw * albedo;
                     li = fmaxf(0.0f, 1.0f - (reflection_intensity + refraction_intensity));   // :625
                     // children: colour is linear in them, so they carry weight w*albedo*intensity.
-                    // Refraction is deferred first so that reflection is evaluated first (:592-605).
+                    // The reflection is evaluated first (:592-605): it becomes the lane's next path ray
+                    // in place (ro/rd/rw are dead from here on); only a second child, the refraction,
+                    // goes to the deferred list.  rnode == 0 afterwards means "no child waiting in place".
+                    const uint32_t parent = rnode;
+                    rnode = 0u;
+                    bool refr_in_place = false;
                     if (cast_refr) {
                         const F3 cw_ = wa * refraction_intensity;
                         if (refract_limit == 0u) sample_col = sample_col + (cw_ * color_sky(S, refr_d));   // :562-564
-                        else if (npend < RT_PENDING_MAX) { Pending& q = pend[npend++]; q.o = hr.p; q.d = refr_d; q.w = cw_; q.limit = refract_limit; q.node = rnode * 2u + 1u; }
+                        else if (!(cast_refl && reflect_limit != 0u)) refr_in_place = true;
+                        else if (npend < RT_PENDING_MAX) { Pending& q = pend[npend++]; q.o = hr.p; q.d = refr_d; q.w = cw_; q.limit = refract_limit; q.node = parent * 2u + 1u; }
                     }
                     if (cast_refl) {
                         const F3 cw_ = wa * reflection_intensity;
                         if (reflect_limit == 0u) sample_col = sample_col + (cw_ * color_sky(S, refl_d));
-                        else if (npend < RT_PENDING_MAX) { Pending& q = pend[npend++]; q.o = hr.p; q.d = refl_d; q.w = cw_; q.limit = reflect_limit; q.node = rnode * 2u; }
+                        else { ro = hr.p; rd = refl_d; rw = cw_; rlimit = reflect_limit; rnode = parent * 2u; }
                     }
+                    if (refr_in_place) { ro = hr.p; rd = refr_d; rw = wa * refraction_intensity; rlimit = refract_limit; rnode = parent * 2u + 1u; }
                     // lights, :608-621
                     hp = hr.p + (hr.normal * RT_BIAS); hn = hr.normal;
                     lsum = f3(0.0f, 0.0f, 0.0f); light_k = 0u;
@@ -764,7 +771,8 @@ render_kernel(const DevSceneView S, const RenderParams P) {
             }
             // stage B: next ray of the current sample's recursion tree
             if (state == NEED_PATH) {
-                if (npend != 0) {
+                if (rnode != 0u) state = PATH;           // the child left in place by the last hit
+                else if (npend != 0) {
                     const Pending& q = pend[--npend];
                     ro = q.o; rd = q.d; rw = q.w; rlimit = q.limit; rnode = q.node;
                     state = PATH;
