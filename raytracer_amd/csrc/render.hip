@@ -526,6 +526,7 @@ struct RenderParams {
     float* partial;                                 // [unit_count][tile][64][3] sums of the clamped samples of each unit (8x8 tiles of the chunk)
     unsigned long long* counters;                   // RtRayCounters on the device (nullable)
     uint32_t refill_lanes;                          // idle lanes that end a traversal burst
+    uint32_t sample_sync;                           // lanes of a wave start their next sample together
     uint32_t* block_counter;                        // next unclaimed block of 64 work items (zeroed per launch)
     const uint32_t* tile_order;                     // k-th tile to hand out, expensive ones first; [-1] = how many are expensive; null = row-major
 #ifdef RT_PHASE_STATS
@@ -783,8 +784,16 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                     s++; state = NEED_SAMPLE;
                 }
             }
+        }
+        // Lanes start their next sample together: a lane whose sample is done waits until no lane of
+        // the wave has a ray of the current sample left.  The rays traced side by side are then of one
+        // kind (camera rays with camera rays, shadow rays with shadow rays), which keeps the lanes in
+        // step through the tree (measured: weekend +5 %, instanced meshes +7 %).
+        const bool sample_in_progress = P.sample_sync && __ballot(tracing || state == PATH || state == SHADOW) != 0ull;
+        if (!tracing && state != NEED_BLOCK && state != FINISHED) {
             // stage C: next sample / next work item
             while (state == NEED_SAMPLE) {
+                if (s < s_end && sample_in_progress) break;
                 if (s < s_end) {
                     PH(PH_STAGE_C);
                     float lx = 0.0f, ly = 0.0f;
@@ -1304,6 +1313,8 @@ int enqueue_accumulate(RtScene* scene, Workspace& ws, const RtSettings* st, cons
     {
         static const uint32_t refill = []() { const char* e = getenv("RT_REFILL_LANES"); int v = e ? atoi(e) : RT_REFILL_LANES; return (uint32_t)(v < 1 ? 1 : (v > 64 ? 64 : v)); }();
         P.refill_lanes = refill;
+        static const uint32_t ssync = []() { const char* e = getenv("RT_SAMPLE_SYNC"); return (uint32_t)(e ? atoi(e) : 1); }();
+        P.sample_sync = ssync;
     }
     // expensive tiles first (whole-segment launches over enough tiles to have a tail worth hiding)
     const uint32_t n_tiles = pix_slots / 64;
