@@ -54,6 +54,7 @@
 #define RT_BLOCK 256
 #endif
 #define RT_PENDING_MAX 8
+#define RT_QUEUES 16u            /* block counters per launch, one cache line each */
 #ifndef RT_WAVES_PER_SIMD
 #define RT_WAVES_PER_SIMD 4     /* register budget of the render kernel: 512 / 4 -> 128 VGPRs */
 #endif
@@ -527,7 +528,7 @@ struct RenderParams {
     unsigned long long* counters;                   // RtRayCounters on the device (nullable)
     uint32_t refill_lanes;                          // idle lanes that end a traversal burst
     uint32_t sample_sync;                           // lanes of a wave start their next sample together
-    uint32_t* block_counter;                        // next unclaimed block of 64 work items (zeroed per launch)
+    uint32_t* block_counter;                        // RT_QUEUES counters, 64 B apart (zeroed per launch): next unclaimed block of each queue
     const uint32_t* tile_order;                     // k-th tile to hand out, expensive ones first; [-1] = how many are expensive; null = row-major
 #ifdef RT_PHASE_STATS
     unsigned long long* phase_stats;                // diagnostics build only: [phase][lane-iterations, wave-iterations]
@@ -581,6 +582,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
     const uint32_t lane = threadIdx.x & 63u;
 
     uint32_t n_primary = 0, n_secondary = 0, n_shadow = 0, n_samples = 0;
+    uint32_t queue = (blockIdx.x * (RT_BLOCK / 64u) + (threadIdx.x >> 6)) % RT_QUEUES;      // this wave's current block counter
 #ifdef RT_PHASE_STATS
     uint32_t ph_lanes[PH_COUNT] = {}, ph_waves[PH_COUNT] = {};
 #endif
@@ -615,11 +617,20 @@ render_kernel(const DevSceneView S, const RenderParams P) {
         // ================= next block of work items: all lanes of the wave together ======
         if (__ballot(state != NEED_BLOCK && state != FINISHED) == 0ull) {
             if (state == NEED_BLOCK) {
-                uint32_t blk = 0;
-                if (lane == 0) blk = atomicAdd(P.block_counter, 1u);
-                blk = __builtin_amdgcn_readfirstlane(blk);
-                // blocks are numbered tile-major: every unit of the first (most expensive) tile, then the next tile
-                if (blk >= (total_items >> 6)) state = FINISHED;      // pix_slots is a multiple of 64
+                // Blocks are handed out by RT_QUEUES counters, counter q owning blocks q, q + RT_QUEUES, ...
+                // (same-address atomics serialise in L2: one counter cost 3 % of the headline frame and
+                // half of a single-sample launch).  A wave starts at its own counter and moves on to the
+                // next one when that is exhausted, so the hand-out order stays "expensive first".
+                const uint32_t total_blocks = total_items >> 6;          // pix_slots is a multiple of 64
+                uint32_t blk = total_blocks;
+                for (uint32_t tries = 0; tries < RT_QUEUES && blk >= total_blocks; tries++) {
+                    uint32_t idx = 0;
+                    if (lane == 0) idx = atomicAdd(P.block_counter + queue * 16u, 1u);
+                    idx = __builtin_amdgcn_readfirstlane(idx);
+                    blk = idx < (total_blocks + RT_QUEUES - 1u) / RT_QUEUES ? idx * RT_QUEUES + queue : total_blocks;      // (guards the multiply)
+                    if (blk >= total_blocks) { blk = total_blocks; queue = (queue + 1u) % RT_QUEUES; }
+                }
+                if (blk >= total_blocks) state = FINISHED;
                 else {
                     // Block numbering: first every unit of each tile whose rays hit something, tile after
                     // tile in cost order (so that the long blocks all start early), then the tiles that
@@ -1177,7 +1188,7 @@ struct Workspace {
     DeviceBuffer partial, accum, out_rgb, out_rgba, ctrl, prim, order;
     int init(bool with_stream) {
         if (with_stream) HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-        return ctrl.ensure(256);
+        return ctrl.ensure(2048);            // [0, 32) ray counters, [1024, 2048) block counters
     }
     void release() {
         if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); stream = nullptr; }
@@ -1339,8 +1350,8 @@ int enqueue_accumulate(RtScene* scene, Workspace& ws, const RtSettings* st, cons
         const uint64_t items = (uint64_t)P.pix_slots * P.unit_count;
         uint64_t blocks = (items + RT_BLOCK - 1) / RT_BLOCK;
         if (blocks > (uint64_t)scene->grid_blocks) blocks = scene->grid_blocks;
-        P.block_counter = (uint32_t*)((char*)ws.ctrl.p + 64);
-        HIP_TRY(hipMemsetAsync(P.block_counter, 0, sizeof(uint32_t), stream));
+        P.block_counter = (uint32_t*)((char*)ws.ctrl.p + 1024);
+        HIP_TRY(hipMemsetAsync(P.block_counter, 0, RT_QUEUES * 64, stream));
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
         bool profiling;
         { std::lock_guard<std::mutex> pg(scene->profile_lock); profiling = scene->profiling; }
