@@ -84,7 +84,6 @@ struct DevSceneView {
     uint32_t tlas_root_ref;
     uint32_t stack_entries;       // per-lane traversal stack depth the trees need
     uint32_t shadow_any_hit;      // no dielectric material in the scene: any occluder ends a shadow ray
-    uint32_t recursive_materials; // some material casts reflection / refraction rays
     uint32_t mesh_entities;       // some entity is a mesh instance (the walk enters BLASes)
     uint32_t loose_boxes;         // some entity rotates about a non-unit axis: its box does not bound its hits, so
                                   // TLAS boxes are tested against the ray's whole interval like the reference does

@@ -1073,10 +1073,9 @@ __global__ void finish_kernel(const float* acc, uint32_t src_pitch, uint32_t sx,
 // of sky.  Tiles are therefore handed out most expensive first, so that the waves still running
 // at the end hold cheap tiles.  Cost class of a tile = what the primary rays through 16 of its
 // pixel centres hit: 0 a dielectric (two child rays per hit), 1 something reflective, 2 anything
-// else, 3 only sky.  The order changes the schedule only, never a pixel.  Scenes without
-// reflective or refractive materials skip it (no long blocks; measured: no gain, 1 % cost).
+// else, 3 only sky.  The order changes the schedule only, never a pixel.
 // Measured on weekend 1080p x 256 spp, per-rank time of the 8-rank strip partition:
-// 7.5-8.0 ms row-major, 6.2-6.5 ms ordered (ideal 6.1); single GPU unchanged.
+// 7.5-8.0 ms row-major, 6.2-6.5 ms ordered (ideal 6.1); Dreadnaught on one GPU 19.97 -> 19.08 ms.
 #define RT_COST_BINS 4u
 __global__ void __launch_bounds__(RT_BLOCK)
 classify_kernel(const DevSceneView S, const RenderParams P, uint32_t n_tiles, uint32_t* tile_bin) {
@@ -1330,7 +1329,7 @@ int enqueue_accumulate(RtScene* scene, Workspace& ws, const RtSettings* st, cons
     // expensive tiles first (whole-segment launches over enough tiles to have a tail worth hiding)
     const uint32_t n_tiles = pix_slots / 64;
     static const bool order_tiles = []() { const char* e = getenv("RT_TILE_ORDER"); return !e || atoi(e) != 0; }();
-    if (!fine && order_tiles && n_tiles >= 256 && scene->view.recursive_materials) {
+    if (!fine && order_tiles && n_tiles >= 256) {
         if ((rc = ws.order.ensure((size_t)n_tiles * 8 + 16))) return rc;
         uint32_t* tile_bin = (uint32_t*)ws.order.p; uint32_t* tile_order = tile_bin + n_tiles + 4;      // [-1] = expensive-tile count
         hipLaunchKernelGGL(classify_kernel, dim3((n_tiles * 16 + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), scene->lds_bytes, stream, scene->view, P,

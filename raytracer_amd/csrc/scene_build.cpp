@@ -401,12 +401,7 @@ int build_flat_scene(const RtSceneDesc* d, FlatScene& out, std::string& err) {
     // scatter yields a refraction, i.e. a MatDielectric; without any, the first hit found decides.
     v.shadow_any_hit = 1;
     for (uint64_t i = 0; i < n_mat; i++) if (d->materials[i].kind == RT_MAT_DIELECTRIC) v.shadow_any_hit = 0;
-    // materials whose hits cast further path rays (materials.rs:45-53, 90-112, 168-204); a scene
-    // without any has no expensive tiles to schedule first (render.hip, classify_kernel)
     v.mesh_entities = d->mesh_object_count ? 1u : 0u;
-    v.recursive_materials = 0;
-    for (uint64_t i = 0; i < n_mat; i++)
-        if (d->materials[i].kind != RT_MAT_LAMBERTIAN || d->materials[i].reflectivity > 0.0f) v.recursive_materials = 1;
     out.materials.resize(n_mat ? n_mat : 1);
     for (uint64_t i = 0; i < n_mat; i++) {
         const RtMaterial& s = d->materials[i]; DevMaterial& m = out.materials[i];
