@@ -214,12 +214,23 @@ def main():
                 traffic = json.load(open(pmc_path)).get(args.workload)
             except Exception:
                 traffic = None
+        # VALU issue time of one launch from the committed PMC pass (profiles/pmc_traffic.json "valu_insts"):
+        # every non-packed VALU wave-instruction holds its SIMD for 4 cycles; 256 CUs x 4 SIMDs at 2.4 GHz
+        valu_issue_ms = None
+        try:
+            valu_insts = json.load(open(pmc_path)).get("valu_insts", {}).get(args.workload) if n_gpus == 1 else None
+            if valu_insts:
+                valu_issue_ms = valu_insts * 4.0 / (256 * 4) / 2.4e9 * 1e3
+        except Exception:
+            valu_issue_ms = None
         result["roofline"] = {
             "bound": "valu", "achieved": round(tflops, 4), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(tflops / VALU_PEAK_TFLOPS, 5), "traffic": traffic if n_gpus == 1 else None,
             "kernel": "render_kernel", "kernel_ms_avg": round(kernel_s * 1e3, 4), "launches": int(launches),
             "flops_per_ray": round(flops_per_ray, 2),
             "per_ray": {k: round(v, 3) for k, v in per_ray.items()}, "traversal_mismatch": int(cn_s.min_mismatch),
+            "valu_issue_ms": None if valu_issue_ms is None else round(valu_issue_ms, 3),
+            "valu_issue_frac": None if valu_issue_ms is None else round(valu_issue_ms / (kernel_s * 1e3), 4),
         }
         result["roofline_hbm"] = {"bound": "hbm", "achieved": round(gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": round(gbs / HBM_PEAK_GBS, 6), "bytes_per_launch": int(hbm_bytes_per_launch),

@@ -54,7 +54,9 @@
 #define RT_BLOCK 256
 #endif
 #define RT_PENDING_MAX 8
+#ifndef RT_QUEUES
 #define RT_QUEUES 16u            /* block counters per launch, one cache line each */
+#endif
 #ifndef RT_WAVES_PER_SIMD
 #define RT_WAVES_PER_SIMD 4     /* register budget of the render kernel: 512 / 4 -> 128 VGPRs */
 #endif
@@ -1187,7 +1189,7 @@ struct Workspace {
     DeviceBuffer partial, accum, out_rgb, out_rgba, ctrl, prim, order;
     int init(bool with_stream) {
         if (with_stream) HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-        return ctrl.ensure(2048);            // [0, 32) ray counters, [1024, 2048) block counters
+        return ctrl.ensure(1024 + RT_QUEUES * 64);      // [0, 32) ray counters, [1024, ...) block counters
     }
     void release() {
         if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); stream = nullptr; }
