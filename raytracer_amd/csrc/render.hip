@@ -1298,8 +1298,9 @@ int enqueue_accumulate(RtScene* scene, Workspace& ws, const RtSettings* st, cons
     // a wave waits for its slowest lane once per 8 samples).  Fine: one item = one sample, for
     // launches that would leave the GPU under-filled or be dominated by their slowest wave
     // (small frames, small chunks).  Same bits either way (see fold_kernel).
-    // Measured (weekend): a full GPU runs the fine split 2x slower (49 -> 98 ms per 1080p frame), an
-    // under-filled one up to 4x faster (400x225x16: 2.48 -> 0.63 ms); so: fine only when the coarse
+    // Measured (weekend): a full GPU runs the fine split 20 % slower (44 -> 54 ms per 1080p frame: eight
+    // times the block claims, scratch writes and fold reads), an under-filled one up to 5x faster
+    // (400x225x16: 2.48 -> 0.52 ms); so: fine only when the coarse
     // blocks would not even occupy the resident waves and no other host call is rendering on this
     // scene at the same time (concurrent chunk calls fill the GPU together).
     const uint64_t coarse_blocks = (uint64_t)(pix_slots / 64) * nseg;
