@@ -21,6 +21,18 @@ ChunkRenderer hip_chunk_renderer(RtScene* scene, RtSettings settings, uint64_t s
     };
 }
 
+ChunkRenderer hip_chunk_renderer(std::vector<RtScene*> scenes, RtSettings settings, uint64_t seed) {
+    auto next = std::make_shared<std::atomic<size_t>>(0);
+    return [scenes, settings, seed, next](const RtRenderChunk& chunk, RgbaBuffer& out, RtRayCounters& rays) -> int {
+        thread_local const void* bound_to = nullptr; thread_local size_t mine = 0;
+        if (bound_to != next.get()) { mine = next->fetch_add(1) % scenes.size(); bound_to = next.get(); }      // first chunk of this thread in this job
+        RtRayCounters c{};
+        const int rc = rt_render_chunk(scenes[mine], &settings, &chunk, seed, nullptr, out.data.data(), &c);
+        rays.primary += c.primary; rays.secondary += c.secondary; rays.shadow += c.shadow; rays.samples += c.samples;
+        return rc;
+    };
+}
+
 namespace {
 
 // render.rs:117-167

@@ -48,6 +48,10 @@ struct RgbaBuffer {
 //   returns 0 or an RT_E_* code; fills `out` (chunk.width x chunk.height) and adds to `rays`.
 using ChunkRenderer = std::function<int(const RtRenderChunk& chunk, RgbaBuffer& out, RtRayCounters& rays)>;
 ChunkRenderer hip_chunk_renderer(RtScene* scene, RtSettings settings, uint64_t seed = RNG_SEED);
+// Several GPUs in one process: `scenes` holds one replica of the scene per device; every worker thread
+// is bound to one of them on its first chunk (round robin), so N x k threads keep N GPUs busy with the
+// reference's own threading model.  The frame does not depend on which GPU rendered which chunk.
+ChunkRenderer hip_chunk_renderer(std::vector<RtScene*> scenes, RtSettings settings, uint64_t seed = RNG_SEED);
 
 struct RenderWork { RtRenderChunk chunk; std::shared_ptr<const ChunkRenderer> render; };
 

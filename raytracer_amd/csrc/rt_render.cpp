@@ -22,14 +22,14 @@ struct Options {
     uint32_t width = 400, height = 225, spp = 16, depth = 8, chunks_x = 4, chunks_y = 4, threads = 2;
     float lens_radius = 0.1f, fov = 45.0f;
     uint64_t seed = RNG_SEED;
-    int device = 0;
+    std::vector<int> devices{0};
     bool self_test = false, list = false;
 };
 
 int usage() {
     fprintf(stderr,
             "usage: rt_render [--scene NAME] [--params \"Key=v;Key=v\"] [--mesh-dir DIR] [--width W] [--height H] [--spp N]\n"
-            "                 [--depth D] [--chunks CXxCY] [--threads T] [--seed S] [--device G] [--lens-radius R] [--fov F]\n"
+            "                 [--depth D] [--chunks CXxCY] [--threads T] [--seed S] [--devices G[,G...]] [--lens-radius R] [--fov F]\n"
             "                 [--out frame.ppm] [--list] [--self-test]\n"
             "  --self-test  exercises the job machinery with a synthetic per-chunk pattern instead of the GPU\n");
     return 2;
@@ -53,7 +53,11 @@ bool parse(int argc, char** argv, Options& o) {
         else if (a == "--depth") o.depth = (uint32_t)atoi(v);
         else if (a == "--threads") o.threads = (uint32_t)atoi(v);
         else if (a == "--seed") o.seed = strtoull(v, nullptr, 10);
-        else if (a == "--device") o.device = atoi(v);
+        else if (a == "--device" || a == "--devices") {           // "0" or "0,1,2,3": one scene replica per entry
+            o.devices.clear();
+            for (const char* p = v; *p;) { o.devices.push_back(atoi(p)); while (*p && *p != ',') p++; if (*p == ',') p++; }
+            if (o.devices.empty()) return false;
+        }
         else if (a == "--lens-radius") o.lens_radius = (float)atof(v);
         else if (a == "--fov") o.fov = (float)atof(v);
         else if (a == "--chunks") { if (sscanf(v, "%ux%u", &o.chunks_x, &o.chunks_y) != 2) return false; }
@@ -82,7 +86,7 @@ int main(int argc, char** argv) {
     chunks.resize((size_t)n_chunks);
 
     RtSceneBuilder* builder = nullptr;
-    RtScene* scene = nullptr;
+    std::vector<RtScene*> scenes;
     ChunkRenderer renderer;
     if (o.self_test) {
         // pattern keyed by the absolute pixel position: any lost, doubled or misplaced chunk shows
@@ -100,9 +104,16 @@ int main(int argc, char** argv) {
         RtCameraConfig cam{(float)o.width, (float)o.height, o.lens_radius, o.fov, 0.0f, 0.0f, 0.0f};
         builder = rt_samples_create(o.scene.c_str(), &cam, o.mesh_dir.c_str(), o.params.empty() ? nullptr : o.params.c_str());
         if (!builder) { fprintf(stderr, "rt_render: %s\n", rt_samples_last_error()); return 1; }   // CreateSceneError, job_constructing.rs:45-53
-        scene = rt_scene_create(rt_builder_desc(builder), o.device);                               // replaces scene.build_bvh(), :92
-        if (!scene) { fprintf(stderr, "rt_render: %s\n", rt_last_error()); rt_builder_destroy(builder); return 1; }
-        renderer = hip_chunk_renderer(scene, settings, o.seed);
+        for (int dev : o.devices) {
+            RtScene* scene = rt_scene_create(rt_builder_desc(builder), dev);                       // replaces scene.build_bvh(), :92
+            if (!scene) {
+                fprintf(stderr, "rt_render: %s\n", rt_last_error());
+                for (RtScene* sc : scenes) rt_scene_destroy(sc);
+                rt_builder_destroy(builder); return 1;
+            }
+            scenes.push_back(scene);
+        }
+        renderer = hip_chunk_renderer(scenes, settings, o.seed);
     }
 
     RenderJob job;
@@ -151,7 +162,7 @@ int main(int argc, char** argv) {
             printf("%s%u", i ? ", " : "", job.worker_handle->thread_handles[i].total_chunks_rendered);
         printf("]}\n");
     }
-    if (scene) rt_scene_destroy(scene);
+    for (RtScene* sc : scenes) rt_scene_destroy(sc);
     if (builder) rt_builder_destroy(builder);
     return status;
 }

@@ -62,6 +62,15 @@ def test_unknown_scene_is_an_error(tmp_path):
 
 
 @pytest.mark.gpu
+def test_scene_replicas_render_the_same_frame(tmp_path):
+    """--devices a,b,...: one scene replica per entry, worker threads bound round robin (here both on GPU 0)."""
+    args = ["--scene", "Mesh", "--width", "160", "--height", "90", "--spp", "4", "--chunks", "5x3", "--threads", "4"]
+    one, img1, _ = run(args + ["--devices", "0"], tmp_path)
+    two, img2, _ = run(args + ["--devices", "0,0"], tmp_path)
+    assert np.array_equal(img1, img2) and one["fnv1a"] == two["fnv1a"] and one["rays"] == two["rays"]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name,params", [("Random Spheres", None), ("Mesh", None)])
 def test_threads_and_chunks_assemble_the_one_call_frame(tmp_path, name, params):
     from raytracer_amd import CameraConfiguration, RenderChunk, RenderSettings, Scene, SceneBuilder
