@@ -57,6 +57,7 @@ WORKLOADS = {
     "dreadnaught-1080p-128spp": ("Dreadnaught", 1920, 1080, 128, 8, 0.1, None),         # configs[2]
     "meshdemo-4k-1024spp": ("Mesh", 3840, 2160, 1024, 8, 0.1, None),                    # configs[3]
     "dootdoot-4k-64spp": ("Doot Doot", 3840, 2160, 64, 8, 0.1, {"Count": 30, "Spacing": 30}),  # configs[4] geometry
+    "dootdoot-4k-4096spp": ("Doot Doot", 3840, 2160, 4096, 8, 0.1, {"Count": 30, "Spacing": 30}),  # configs[4] in full (~30 s per frame on one GPU)
 }
 
 
@@ -189,8 +190,9 @@ def main():
         # (1) per-ray work of the ordered, shrinking traversal (algorithmic minimum), low spp
         st_stats = RenderSettings(W, H, depth, min(spp, 4))
         stride_stats = 13
-        cn_s, _ = oracle.render_chunks_mt(st_stats, grid, 5, stride_stats, (n_chunks - 6) // stride_stats, threads,
-                                          rng_mode=ORC_RNG_COUNTER, seed=seed, stats=True)
+        cn_s, ms_s = oracle.render_chunks_mt(st_stats, grid, 5, stride_stats, (n_chunks - 6) // stride_stats, threads,
+                                             rng_mode=ORC_RNG_COUNTER, seed=seed, stats=True)
+        cpu_samples_per_s = cn_s.rays.samples / max(ms_s, 1e-3) * 1e3 * 2.0      # the statistics run traverses twice
         r_s = cn_s.rays.primary + cn_s.rays.secondary + cn_s.rays.shadow
         per_ray = {k: getattr(cn_s, "min_" + k) / r_s for k in ("nodes", "spheres", "planes", "tris", "xforms", "instances")}
         hits_per_ray = (cn_s.rays.primary + cn_s.rays.secondary) / r_s          # shading happens per path ray
@@ -239,8 +241,9 @@ def main():
                                   "on_chip_gather_GBps": round(gather_bytes_per_ray * rays_per_launch / kernel_s / 1e9, 1)}
     # (2) the reference's multithreaded CPU path, bounded sample of the same frame: N = 1 only
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
-        # about 6e8 samples (10-20 s on 16 host threads)
-        stride = args.cpu_chunk_stride or max(1, int(round(W * H * spp / 6.0e8)))
+        # about 6e8 samples (10-20 s on 16 host threads), fewer on scenes where that would take over ~20 s
+        target = min(6.0e8, max(2.0e6, cpu_samples_per_s * 20.0))
+        stride = args.cpu_chunk_stride or max(1, int(round(W * H * spp / target)))
         count = (n_chunks - 1) // stride
         cn_b, ms_b = oracle.render_chunks_mt(settings, grid, 0, stride, count, threads, rng_mode=ORC_RNG_XORSHIFT_CHUNK,
                                              seed=seed)
