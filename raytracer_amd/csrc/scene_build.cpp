@@ -13,6 +13,7 @@
 // (device_scene.h) with objects re-ordered into leaf order.
 #include "scene_build.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 
@@ -161,6 +162,125 @@ struct Emitter {
     }
 };
 
+// ---------------------------------------------------------------------------
+// The tree the GPU walks: binned SAH over the REFERENCE's leaves
+// ---------------------------------------------------------------------------
+// Which objects the reference tests for a ray is decided by the leaf boxes alone: a leaf's
+// objects are candidates iff the leaf's box and all its ancestors' boxes pass hit_aabb
+// (bvh.rs:210-236), every ancestor box is the exact union (component-wise min / max) of the boxes
+// below it, and hit_aabb is monotone under box containment (f32 subtraction, multiplication by
+// a fixed sign and max / min are monotone; a NaN product - plane through the origin of an
+// axis-parallel ray - is ignored, never restrictive), so a leaf box that passes implies that all
+// its ancestors pass.  Any tree over the same leaves whose inner boxes are exact unions therefore
+// yields the same candidates, and the hit is chosen by (t, reference visit rank), not by visiting
+// order.  So the device tree is built for walking cost, not copied from the reference's
+// mean-split topology; the reference tree still provides the leaves, their boxes and the ranks.
+struct LeafRec { Box box; uint32_t first, count; };
+
+double clamp30(float v) { return v != v ? 0.0 : (v > 1.0e30f ? 1.0e30 : (v < -1.0e30f ? -1.0e30 : (double)v)); }
+double half_area(const double lo[3], const double hi[3]) {
+    const double dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+
+Tree build_walk_tree(const Tree& ref) {
+    std::vector<LeafRec> leaves;
+    for (const TreeNode& n : ref.nodes) if (n.left < 0) leaves.push_back(LeafRec{n.box, n.first, n.count});
+    Tree t;
+    const uint32_t n_leaves = (uint32_t)leaves.size();
+    std::vector<uint32_t> ids(n_leaves);
+    for (uint32_t i = 0; i < n_leaves; i++) ids[i] = i;
+    std::vector<double> cen((size_t)n_leaves * 3);
+    for (uint32_t i = 0; i < n_leaves; i++) {
+        const Box& b = leaves[i].box;
+        cen[3 * i] = 0.5 * (clamp30(b.lo.x) + clamp30(b.hi.x)); cen[3 * i + 1] = 0.5 * (clamp30(b.lo.y) + clamp30(b.hi.y));
+        cen[3 * i + 2] = 0.5 * (clamp30(b.lo.z) + clamp30(b.hi.z));
+    }
+    t.nodes.reserve((size_t)n_leaves * 2);
+    struct Job { uint32_t node, lo, hi; };
+    std::vector<Job> todo;
+    t.nodes.push_back(TreeNode{Box{}, 0, 0, -1, -1});
+    todo.push_back(Job{0, 0, n_leaves});
+    constexpr int BINS = 16;
+    while (!todo.empty()) {
+        const Job j = todo.back(); todo.pop_back();
+        const uint32_t n = j.hi - j.lo;
+        // exact union of the leaf boxes of the range
+        Box bx = leaves[ids[j.lo]].box;
+        for (uint32_t k = j.lo + 1; k < j.hi; k++) { grow(bx, leaves[ids[k]].box.lo); grow(bx, leaves[ids[k]].box.hi); }
+        t.nodes[j.node].box = bx;
+        if (n == 1) { const LeafRec& l = leaves[ids[j.lo]]; t.nodes[j.node].first = l.first; t.nodes[j.node].count = l.count; continue; }
+        // binned SAH on the centroids
+        double cb_lo[3] = {1e300, 1e300, 1e300}, cb_hi[3] = {-1e300, -1e300, -1e300};
+        for (uint32_t k = j.lo; k < j.hi; k++) for (int a = 0; a < 3; a++) {
+            const double c = cen[3 * (size_t)ids[k] + a];
+            if (c < cb_lo[a]) cb_lo[a] = c;
+            if (c > cb_hi[a]) cb_hi[a] = c;
+        }
+        double best_cost = 1e300; int best_axis = -1, best_split = 0;
+        for (int a = 0; a < 3; a++) {
+            const double ext = cb_hi[a] - cb_lo[a];
+            if (!(ext > 0.0)) continue;
+            double blo[BINS][3], bhi[BINS][3]; uint64_t bcnt[BINS];
+            for (int b = 0; b < BINS; b++) { bcnt[b] = 0; for (int c = 0; c < 3; c++) { blo[b][c] = 1e300; bhi[b][c] = -1e300; } }
+            for (uint32_t k = j.lo; k < j.hi; k++) {
+                const LeafRec& l = leaves[ids[k]];
+                int b = (int)((cen[3 * (size_t)ids[k] + a] - cb_lo[a]) / ext * BINS); if (b >= BINS) b = BINS - 1; if (b < 0) b = 0;
+                bcnt[b] += l.count;
+                const double lo3[3] = {clamp30(l.box.lo.x), clamp30(l.box.lo.y), clamp30(l.box.lo.z)}, hi3[3] = {clamp30(l.box.hi.x), clamp30(l.box.hi.y), clamp30(l.box.hi.z)};
+                for (int c = 0; c < 3; c++) { if (lo3[c] < blo[b][c]) blo[b][c] = lo3[c]; if (hi3[c] > bhi[b][c]) bhi[b][c] = hi3[c]; }
+            }
+            double right_area[BINS]; uint64_t right_cnt[BINS];
+            double rlo[3] = {1e300, 1e300, 1e300}, rhi[3] = {-1e300, -1e300, -1e300}; uint64_t rc = 0;
+            for (int b = BINS - 1; b > 0; b--) {
+                if (bcnt[b]) for (int c = 0; c < 3; c++) { if (blo[b][c] < rlo[c]) rlo[c] = blo[b][c]; if (bhi[b][c] > rhi[c]) rhi[c] = bhi[b][c]; }
+                rc += bcnt[b]; right_cnt[b] = rc; right_area[b] = rc ? half_area(rlo, rhi) : 0.0;
+            }
+            double llo[3] = {1e300, 1e300, 1e300}, lhi[3] = {-1e300, -1e300, -1e300}; uint64_t lc = 0;
+            for (int b = 0; b + 1 < BINS; b++) {
+                if (bcnt[b]) for (int c = 0; c < 3; c++) { if (blo[b][c] < llo[c]) llo[c] = blo[b][c]; if (bhi[b][c] > lhi[c]) lhi[c] = bhi[b][c]; }
+                lc += bcnt[b];
+                if (lc == 0 || right_cnt[b + 1] == 0) continue;
+                const double cost = half_area(llo, lhi) * (double)lc + right_area[b + 1] * (double)right_cnt[b + 1];
+                if (cost < best_cost) { best_cost = cost; best_axis = a; best_split = b + 1; }
+            }
+        }
+        uint32_t mid = j.lo + n / 2;                            // no usable split (coincident centroids): halve the range
+        if (best_axis >= 0) {
+            const double ext = cb_hi[best_axis] - cb_lo[best_axis];
+            uint32_t* first = ids.data() + j.lo; uint32_t* last = ids.data() + j.hi;
+            uint32_t* m = std::partition(first, last, [&](uint32_t id) {
+                int b = (int)((cen[3 * (size_t)id + best_axis] - cb_lo[best_axis]) / ext * BINS); if (b >= BINS) b = BINS - 1; if (b < 0) b = 0;
+                return b < best_split;
+            });
+            const uint32_t pm = (uint32_t)(m - ids.data());
+            if (pm > j.lo && pm < j.hi) mid = pm;
+        }
+        const int32_t l = (int32_t)t.nodes.size();
+        t.nodes.push_back(TreeNode{Box{}, 0, 0, -1, -1});
+        t.nodes.push_back(TreeNode{Box{}, 0, 0, -1, -1});
+        t.nodes[j.node].left = l; t.nodes[j.node].right = l + 1;
+        todo.push_back(Job{(uint32_t)l, j.lo, mid});
+        todo.push_back(Job{(uint32_t)l + 1, mid, j.hi});
+    }
+    return t;
+}
+
+// Depth of the node array the Emitter would produce for `t` (inner levels on the longest path)
+uint32_t emitted_depth(const Tree& t) {
+    uint32_t depth = 0;
+    std::vector<std::pair<int32_t, uint32_t>> st{{0, 0}};
+    while (!st.empty()) {
+        const auto [ni, level] = st.back(); st.pop_back();
+        const TreeNode& n = t.nodes[ni];
+        if (n.left >= 0) { st.push_back({n.left, level + 1}); st.push_back({n.right, level + 1}); continue; }
+        uint32_t extra = 0;
+        for (uint32_t c = n.count; c > RT_LEAF_MAX; c = c - c / 2) extra++;      // emit_leaf halves: the larger half decides
+        if (level + extra > depth) depth = level + extra;
+    }
+    return depth;
+}
+
 int bad(std::string& err, const std::string& msg) { err = msg; return RT_E_INVALID; }
 
 }  // namespace
@@ -286,16 +406,22 @@ int build_flat_scene(const RtSceneDesc* d, FlatScene& out, std::string& err) {
 
     // ---- emit nodes -------------------------------------------------------------
     out.nodes.clear();
-    Emitter te{out.nodes, 0, tlas};
+    static const bool walk_trees = []() { const char* e = getenv("RT_WALK_TREE"); return !e || atoi(e) != 0; }();      // 0: walk the reference's own topology
+    constexpr uint32_t kMaxWalkDepth = 26;                  // keeps the LDS stack of TLAS + BLAS within 64 KB
+    Tree tlas_walk;
+    bool tlas_own = false;
+    if (walk_trees) { tlas_walk = build_walk_tree(tlas); tlas_own = emitted_depth(tlas_walk) <= std::max(kMaxWalkDepth, emitted_depth(tlas)); }
+    Emitter te{out.nodes, 0, tlas_own ? tlas_walk : tlas};
     v.tlas_root_ref = te.emit(0, 0);
     put3(v.tlas_min, RtV3{tlas.nodes[0].box.lo.x, tlas.nodes[0].box.lo.y, tlas.nodes[0].box.lo.z});
     put3(v.tlas_max, RtV3{tlas.nodes[0].box.hi.x, tlas.nodes[0].box.hi.y, tlas.nodes[0].box.hi.z});
     out.info.tlas_node_count = out.nodes.size();
-    out.info.tlas_depth = te.depth;
+    out.info.tlas_depth = emitted_depth(tlas);             // of the reference-shaped tree
+    const uint32_t tlas_walk_depth = te.depth;
 
     out.meshes.resize(n_mesh);
     out.blas_order.resize(n_mesh);
-    uint32_t blas_depth = 0;
+    uint32_t blas_depth = 0, blas_walk_depth = 0;
     uint64_t tri_total = 0;
     std::vector<uint32_t> pos_order;
     for (uint64_t m = 0; m < n_mesh; m++) {
@@ -303,9 +429,13 @@ int build_flat_scene(const RtSceneDesc* d, FlatScene& out, std::string& err) {
         const Tree& t = blas[m];
         const uint32_t node_base = (uint32_t)out.nodes.size();
         const uint32_t tri_base = (uint32_t)out.tri_hot.size();
-        Emitter be{out.nodes, node_base, t};
+        Tree walk;
+        bool own = false;
+        if (walk_trees) { walk = build_walk_tree(t); own = emitted_depth(walk) <= std::max(kMaxWalkDepth, emitted_depth(t)); }
+        Emitter be{out.nodes, node_base, own ? walk : t};
         const uint32_t root = be.emit(0, 0);
-        if (be.depth > blas_depth) blas_depth = be.depth;
+        if (be.depth > blas_walk_depth) blas_walk_depth = be.depth;
+        blas_depth = std::max(blas_depth, emitted_depth(t));
         DevMesh& dm = out.meshes[m];
         dm.w[0].u[0] = node_base; dm.w[0].u[1] = tri_base; dm.w[0].u[2] = (uint32_t)mesh.tri_count; dm.w[0].u[3] = root;
         const Box& rb = t.nodes[0].box;
@@ -434,7 +564,7 @@ int build_flat_scene(const RtSceneDesc* d, FlatScene& out, std::string& err) {
 
     // traversal stack: one deferred sibling per inner level of the TLAS, one
     // TLAS-leaf continuation, one per inner level of the deepest BLAS, + margin
-    v.stack_entries = out.info.tlas_depth + 1 + out.info.blas_depth + 2;
+    v.stack_entries = tlas_walk_depth + 1 + blas_walk_depth + 2;
     return RT_OK;
 }
 
