@@ -175,6 +175,9 @@ struct Emitter {
 // yields the same candidates, and the hit is chosen by (t, reference visit rank), not by visiting
 // order.  So the device tree is built for walking cost, not copied from the reference's
 // mean-split topology; the reference tree still provides the leaves, their boxes and the ranks.
+#ifndef RT_SAH_BINS
+#define RT_SAH_BINS 64
+#endif
 struct LeafRec { Box box; uint32_t first, count; };
 
 double clamp30(float v) { return v != v ? 0.0 : (v > 1.0e30f ? 1.0e30 : (v < -1.0e30f ? -1.0e30 : (double)v)); }
@@ -201,7 +204,7 @@ Tree build_walk_tree(const Tree& ref) {
     std::vector<Job> todo;
     t.nodes.push_back(TreeNode{Box{}, 0, 0, -1, -1});
     todo.push_back(Job{0, 0, n_leaves});
-    constexpr int BINS = 16;
+    constexpr int BINS = RT_SAH_BINS;
     while (!todo.empty()) {
         const Job j = todo.back(); todo.pop_back();
         const uint32_t n = j.hi - j.lo;
