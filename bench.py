@@ -244,13 +244,19 @@ def main():
         # about 6e8 samples (10-20 s on 16 host threads), fewer on scenes where that would take over ~20 s
         target = min(6.0e8, max(2.0e6, cpu_samples_per_s * 20.0))
         stride = args.cpu_chunk_stride or max(1, int(round(W * H * spp / target)))
+        if stride > 4:          # a sparse sample: many small chunks spread over the frame instead of a few large ones
+            grid = (128, 128)
+            n_chunks = grid[0] * grid[1]
+            stride = max(1, int(round(W * H * spp / target)))
+            if stride % 128 == 0 or stride % 2 == 0:
+                stride += 1     # odd and not a multiple of the row length: the picks walk across rows and columns
         count = (n_chunks - 1) // stride
-        cn_b, ms_b = oracle.render_chunks_mt(settings, grid, 0, stride, count, threads, rng_mode=ORC_RNG_XORSHIFT_CHUNK,
+        cn_b, ms_b = oracle.render_chunks_mt(settings, grid, stride // 2, stride, count, threads, rng_mode=ORC_RNG_XORSHIFT_CHUNK,
                                              seed=seed)
         r_b = cn_b.rays.primary + cn_b.rays.secondary + cn_b.rays.shadow
         result["cpu_baseline"] = {
             "value": round(r_b / ms_b / 1e3, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "sample": f"{count} of {n_chunks} chunks (32x32 grid, every {stride}th) of the same frame at full spp, "
+            "sample": f"{count} of {n_chunks} chunks ({grid[0]}x{grid[1]} grid, every {stride}th) of the same frame at full spp, "
                       f"{cn_b.rays.samples} samples, {ms_b / 1e3:.1f} s; oracle/rt_oracle.cpp -O2 -ffp-contract=off, "
                       f"{threads} std::threads pulling chunks (src/render.rs:186-224), per-chunk XorShift RNG",
             "msamples_per_s": round(cn_b.rays.samples / ms_b / 1e3, 3),
