@@ -47,9 +47,8 @@
 // A work item is one pixel x one segment: 8 measured best on MI355X (32 / 16 / 8 / 4:
 // 57.4 / 53.5 / 52.7 / 56.9 ms for the weekend 1080p 256 spp frame; smaller items
 // shorten the tail of a launch, larger ones amortise the per-item set-up).
-#ifndef RT_SAMPLE_SEGMENT
-#define RT_SAMPLE_SEGMENT 8u
-#endif
+#define RT_SEGMENT_SHIFT 3u
+#define RT_SAMPLE_SEGMENT (1u << RT_SEGMENT_SHIFT)
 #ifndef RT_BLOCK
 #define RT_BLOCK 256
 #endif
@@ -134,9 +133,9 @@ __device__ __forceinline__ float u32_to_f32(uint32_t v) { return (float)(v >> 8)
 
 // the two draws every consumer on this path needs (lens jitter: implementation.rs:649-650;
 // random_normal_reflection_angle: :17-18)
-__device__ __forceinline__ void rng_pair(uint64_t seed, uint32_t px, uint32_t py, uint32_t sample, uint32_t node, uint32_t purpose, float& r0, float& r1) {
+__device__ __forceinline__ void rng_pair(uint64_t seed, uint32_t pxy, uint32_t sample, uint32_t node, uint32_t purpose, float& r0, float& r1) {
     uint32_t o[4];
-    philox4x32_10(px | (py << 16), sample, node, purpose, (uint32_t)seed, (uint32_t)(seed >> 32), o);
+    philox4x32_10(pxy, sample, node, purpose, (uint32_t)seed, (uint32_t)(seed >> 32), o);
     r0 = u32_to_f32(o[0]); r1 = u32_to_f32(o[1]);
 }
 
@@ -529,7 +528,6 @@ struct RenderParams {
     float* partial;                                 // [unit_count][tile][64][3] sums of the clamped samples of each unit (8x8 tiles of the chunk)
     unsigned long long* counters;                   // RtRayCounters on the device (nullable)
     uint32_t refill_lanes;                          // idle lanes that end a traversal burst
-    uint32_t sample_sync;                           // lanes of a wave start their next sample together
     uint32_t* block_counter;                        // RT_QUEUES counters, 64 B apart (zeroed per launch): next unclaimed block of each queue
     const uint32_t* tile_order;                     // k-th tile to hand out, expensive ones first; [-1] = how many are expensive; null = row-major
 #ifdef RT_PHASE_STATS
@@ -594,9 +592,10 @@ render_kernel(const DevSceneView S, const RenderParams P) {
     enum { PATH = 0, SHADOW = 1, NEED_LIGHT = 2, NEED_PATH = 3, NEED_SAMPLE = 4, NEED_BLOCK = 5, FINISHED = 6 };
     int state = NEED_BLOCK;
     bool tracing = false;
-    uint32_t px = 0, py = 0, s = 0, s_end = 0, out_slot = 0;
-    float pu = 0.0f, pv = 0.0f;
-    F3 seg_sum = f3(0, 0, 0), sample_col = f3(0, 0, 0);
+    uint32_t pxy = 0, s = RT_NONE;           // pixel (x | y << 16) and sample index of the lane's current round (RT_NONE: no sample)
+    // the wave's current block (wave-uniform): tile, unit, rounds started
+    uint32_t blk_tile = 0, blk_unit = 0, round_next = 0;
+    F3 sample_col = f3(0, 0, 0);
     Pending pend[RT_PENDING_MAX]; uint32_t npend = 0;
     F3 ro = f3(0, 0, 0), rd = f3(0, 0, 1), rw = f3(0, 0, 0); uint32_t rlimit = 0, rnode = 0;   // current path ray
     F3 hp = f3(0, 0, 0), hn = f3(0, 0, 0), wa = f3(0, 0, 0), lsum = f3(0, 0, 0);                  // light phase
@@ -618,7 +617,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
         PH(PH_OUTER);
         // ================= next block of work items: all lanes of the wave together ======
         if (__ballot(state != NEED_BLOCK && state != FINISHED) == 0ull) {
-            if (state == NEED_BLOCK) {
+            if (__ballot(state == NEED_BLOCK) != 0ull) {          // (all lanes of a wave are in the same of the two states)
                 // Blocks are handed out by RT_QUEUES counters, counter q owning blocks q, q + RT_QUEUES, ...
                 // (same-address atomics serialise in L2: one counter cost 3 % of the headline frame and
                 // half of a single-sample launch).  A wave starts at its own counter and moves on to the
@@ -642,20 +641,10 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                     uint32_t tile_rank, unit_local;
                     if (blk < heavy_blocks) { tile_rank = blk / P.unit_count; unit_local = blk % P.unit_count; }
                     else { const uint32_t b = blk - heavy_blocks, rest = n_tiles - heavy; unit_local = b / rest; tile_rank = heavy + b % rest; }
-                    const uint32_t tile = P.tile_order ? P.tile_order[tile_rank] : tile_rank, within = lane;
-                    const uint32_t x = (tile % P.tiles_x) * 8u + (within & 7u), y = (tile / P.tiles_x) * 8u + (within >> 3);
-                    if (x < P.cw && y < P.ch) {       // lanes off the chunk's edge sit this block out
-                        const uint32_t sa = (P.unit_first + unit_local) * P.unit_len, sb = sa + P.unit_len;
-                        const uint32_t r_end = P.sample_first + P.sample_count;
-                        s = sa > P.sample_first ? sa : P.sample_first;
-                        s_end = sb < r_end ? sb : r_end;
-                        px = P.left + x;
-                        py = P.strip_h ? P.strip_first_row + (y / P.strip_h) * P.strip_period_rows + (y % P.strip_h) : P.top + y;
-                        pixel_uv(P, px, py, pu, pv);
-                        out_slot = (unit_local * n_tiles + tile) * 64u + within;      // one block = 768 contiguous bytes
-                        seg_sum = f3(0.0f, 0.0f, 0.0f);
-                        state = NEED_SAMPLE;
-                    }
+                    blk_tile = P.tile_order ? P.tile_order[tile_rank] : tile_rank;
+                    blk_unit = unit_local;
+                    round_next = 0u; s = RT_NONE;         // the block's rays are dealt to the lanes round by round, below
+                    state = NEED_SAMPLE;
                 }
             }
             if (__ballot(state != FINISHED) == 0ull) break;      // the wave has no blocks left
@@ -707,14 +696,14 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                     if (m0.u[0] == RT_MAT_LAMBERTIAN) {                                       // materials.rs:44-53
                         has_refl = true; refl_i = m0.f[1];
                         if (refl_i > 0.0f) {      // the direction is only ever used when the ray is cast (:593)
-                            float r0, r1; rng_pair(P.seed, px, py, s, rnode, PURPOSE_PATH, r0, r1);
+                            float r0, r1; rng_pair(P.seed, pxy, s, rnode, PURPOSE_PATH, r0, r1);
                             refl_d = random_normal_reflection_angle(hr.normal, r0, r1);
                         }
                     } else if (m0.u[0] == RT_MAT_SPECULAR) {                                  // materials.rs:89-112
                         const F3 reflected = reflect(rd, hr.normal);
                         F3 scattered = reflected;
                         if (m0.f[2] != 0.0f) {
-                            float r0, r1; rng_pair(P.seed, px, py, s, rnode, PURPOSE_PATH, r0, r1);
+                            float r0, r1; rng_pair(P.seed, pxy, s, rnode, PURPOSE_PATH, r0, r1);
                             scattered = reflected + (unit(random_normal_reflection_angle(hr.normal, r0, r1)) * m0.f[2]);
                         }
                         if (dot(scattered, hr.normal) > 0.0f) { has_refl = true; refl_d = scattered; refl_i = m0.f[1]; }
@@ -792,26 +781,66 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                     state = PATH;
                 } else {
                     // cast_ray's clamp (:635, types.rs:46-50) then col = col + sample (:656)
-                    const F3 c = f3(fmaxf(fminf(sample_col.x, 1.0f), -1.0f), fmaxf(fminf(sample_col.y, 1.0f), -1.0f), fmaxf(fminf(sample_col.z, 1.0f), -1.0f));
-                    seg_sum = seg_sum + c;
-                    s++; state = NEED_SAMPLE;
+                    // (the sum over the samples is formed when the round ends, below)
+                    sample_col = f3(fmaxf(fminf(sample_col.x, 1.0f), -1.0f), fmaxf(fminf(sample_col.y, 1.0f), -1.0f), fmaxf(fminf(sample_col.z, 1.0f), -1.0f));
+                    state = NEED_SAMPLE;
                 }
             }
         }
-        // Lanes start their next sample together: a lane whose sample is done waits until no lane of
-        // the wave has a ray of the current sample left.  The rays traced side by side are then of one
-        // kind (camera rays with camera rays, shadow rays with shadow rays), which keeps the lanes in
-        // step through the tree (measured: weekend +5 %, instanced meshes +7 %).
-        const bool sample_in_progress = P.sample_sync && __ballot(tracing || state == PATH || state == SHADOW) != 0ull;
-        if (!tracing && state != NEED_BLOCK && state != FINISHED) {
-            // stage C: next sample / next work item
-            while (state == NEED_SAMPLE) {
-                if (s < s_end && sample_in_progress) break;
-                if (s < s_end) {
+        // ================= rounds =====================================================================
+        // A block = the 64 pixels of one 8x8 tile x the samples of one unit.  The wave traces it in rounds
+        // of 64 rays and every lane waits for the round to end, so the rays traced side by side are of one
+        // kind (camera rays with camera rays, shadow rays with shadow rays), which keeps the lanes in step
+        // through the tree (measured against free-running lanes: weekend +5 %, mesh_demo +41 %).
+        // A round is ALL samples of the unit for 64 / unit_len pixels (whole-segment units: the 8 samples of
+        // one row of the tile, lane = sample * 8 + column; one-sample units: all 64 pixels).  Samples of one
+        // pixel meet the same materials, so the lanes of a round have paths of similar length, and a wave
+        // waits for the longest path of 8 pixels instead of 64 (measured against one sample of 64 pixels
+        // per round: weekend +2 %, Dreadnaught +13 %, instanced meshes +24 %).
+        // The clamped samples of a pixel are added in sample order, ((0 + c0) + c1) + ..., by handing them to
+        // the pixel's first lane one after the other (cast_rays_into_scene's col = col + sample, :656).
+        if (__ballot(tracing || state != NEED_SAMPLE) == 0ull) {        // wave-uniform: every lane has finished its sample
+            const uint32_t Q = P.unit_len;                              // 1 or RT_SAMPLE_SEGMENT
+            const uint32_t pg_shift = Q == 1u ? 6u : 6u - RT_SEGMENT_SHIFT, PG = 1u << pg_shift;
+            const uint32_t j = lane >> pg_shift, q = lane & (PG - 1u);
+            const uint32_t x0 = (blk_tile % P.tiles_x) * 8u, y0 = (blk_tile / P.tiles_x) * 8u;
+            const uint32_t sa = (P.unit_first + blk_unit) * Q, sb = sa + Q, r_end = P.sample_first + P.sample_count;
+            const uint32_t s_lo = sa > P.sample_first ? sa : P.sample_first, s_hi = sb < r_end ? sb : r_end;
+            // pixel (y * 8 + x within the tile) of this lane in pixel group g: the groups of a whole-segment
+            // unit are 4x2 pixels, which keeps the rays of a round closer together than a row of 8
+            auto group_pixel = [&](uint32_t g) -> uint32_t {
+                if (Q == 1u) return q;
+                return (((g >> 1) << 1) | (q >> 2)) * 8u + (((g & 1u) << 2) | (q & 3u));
+            };
+            for (;;) {
+                if (round_next != 0u) {
+                    // close the round: segment sums of its pixels
+                    const F3 c = s != RT_NONE ? sample_col : f3(0.0f, 0.0f, 0.0f);     // (x + 0 == x: the sum is never -0)
+                    F3 sum = f3(0.0f, 0.0f, 0.0f);
+                    for (uint32_t jj = 0; jj < Q; jj++) {
+                        const int src = (int)(q + (jj << pg_shift));
+                        sum = sum + f3(__shfl(c.x, src, 64), __shfl(c.y, src, 64), __shfl(c.z, src, 64));
+                    }
+                    const uint32_t within = group_pixel(round_next - 1u);
+                    if (j == 0u && x0 + (within & 7u) < P.cw && y0 + (within >> 3) < P.ch) {
+                        float* out = P.partial + ((uint64_t)(blk_unit * (P.pix_slots >> 6) + blk_tile) * 64u + within) * 3;     // one block = 768 contiguous bytes
+                        out[0] = sum.x; out[1] = sum.y; out[2] = sum.z;
+                    }
+                }
+                if (round_next == Q) { state = NEED_BLOCK; break; }      // wait for the wave's next block
+                const uint32_t within = group_pixel(round_next);
+                round_next++;
+                const uint32_t x = x0 + (within & 7u), y = y0 + (within >> 3);
+                s = (x < P.cw && y < P.ch && s_lo + j < s_hi) ? s_lo + j : RT_NONE;      // lanes off the chunk's edge sit the round out
+                if (s != RT_NONE) {
                     PH(PH_STAGE_C);
+                    const uint32_t px = P.left + x;
+                    const uint32_t py = P.strip_h ? P.strip_first_row + (y / P.strip_h) * P.strip_period_rows + (y % P.strip_h) : P.top + y;
+                    pxy = px | (py << 16);
+                    float pu, pv; pixel_uv(P, px, py, pu, pv);
                     float lx = 0.0f, ly = 0.0f;
                     if (P.spp > 1) {                                                  // :648-653
-                        float r0, r1; rng_pair(P.seed, px, py, s, 0u, PURPOSE_LENS, r0, r1);
+                        float r0, r1; rng_pair(P.seed, pxy, s, 0u, PURPOSE_LENS, r0, r1);
                         lx = r0 * 2.0f - 1.0f; ly = r1 * 2.0f - 1.0f;
                     }
                     gen_camera_ray(S, pu, pv, lx, ly, ro, rd);
@@ -819,16 +848,13 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                     sample_col = f3(0.0f, 0.0f, 0.0f); npend = 0; n_samples++;
                     if (rlimit == 0) {                                                // :562-564: sky, no ray cast
                         const F3 sky = color_sky(S, rd);
-                        seg_sum = seg_sum + f3(fmaxf(fminf(sky.x, 1.0f), -1.0f), fmaxf(fminf(sky.y, 1.0f), -1.0f), fmaxf(fminf(sky.z, 1.0f), -1.0f));
-                        s++;
+                        sample_col = f3(fmaxf(fminf(sky.x, 1.0f), -1.0f), fmaxf(fminf(sky.y, 1.0f), -1.0f), fmaxf(fminf(sky.z, 1.0f), -1.0f));
                     } else state = PATH;
-                    continue;
                 }
-                // the item is done: store its segment sum and wait for the wave's next block
-                float* out = P.partial + (uint64_t)out_slot * 3;
-                out[0] = seg_sum.x; out[1] = seg_sum.y; out[2] = seg_sum.z;
-                state = NEED_BLOCK;
+                if (__ballot(state == PATH) != 0ull) break;      // (a round without a single ray: go on to the next)
             }
+        }
+        if (!tracing && state != NEED_BLOCK && state != FINISHED) {
             // ================= start the traversal of the new ray ==========================
             if (state == PATH || state == SHADOW) {
                 PH(PH_TRACE_INIT);
@@ -1326,8 +1352,6 @@ int enqueue_accumulate(RtScene* scene, Workspace& ws, const RtSettings* st, cons
     {
         static const uint32_t refill = []() { const char* e = getenv("RT_REFILL_LANES"); int v = e ? atoi(e) : RT_REFILL_LANES; return (uint32_t)(v < 1 ? 1 : (v > 64 ? 64 : v)); }();
         P.refill_lanes = refill;
-        static const uint32_t ssync = []() { const char* e = getenv("RT_SAMPLE_SYNC"); return (uint32_t)(e ? atoi(e) : 1); }();
-        P.sample_sync = ssync;
     }
     // expensive tiles first (whole-segment launches over enough tiles to have a tail worth hiding)
     const uint32_t n_tiles = pix_slots / 64;
