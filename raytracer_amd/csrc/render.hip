@@ -524,6 +524,7 @@ struct RenderParams {
     uint32_t sample_first, sample_count;            // absolute sample index range to render
     uint32_t unit_len;                              // samples per work item: RT_SAMPLE_SEGMENT (coarse) or 1 (fine)
     uint32_t unit_first, unit_count;                // units (absolute index = sample / unit_len) covered by this launch
+    uint32_t round_units_shift;                     // log2 of the units whose samples share a round (divides unit_count)
     uint32_t tiles_x, pix_slots;                    // 8x8 tiling of the chunk; pix_slots = tiles*64
     float* partial;                                 // [unit_count][tile][64][3] sums of the clamped samples of each unit (8x8 tiles of the chunk)
     unsigned long long* counters;                   // RtRayCounters on the device (nullable)
@@ -800,38 +801,42 @@ render_kernel(const DevSceneView S, const RenderParams P) {
         // The clamped samples of a pixel are added in sample order, ((0 + c0) + c1) + ..., by handing them to
         // the pixel's first lane one after the other (cast_rays_into_scene's col = col + sample, :656).
         if (__ballot(tracing || state != NEED_SAMPLE) == 0ull) {        // wave-uniform: every lane has finished its sample
-            const uint32_t Q = P.unit_len;                              // 1 or RT_SAMPLE_SEGMENT
-            const uint32_t pg_shift = Q == 1u ? 6u : 6u - RT_SEGMENT_SHIFT, PG = 1u << pg_shift;
-            const uint32_t j = lane >> pg_shift, q = lane & (PG - 1u);
+            // lane = (unit of the group, sample of the unit, pixel of the round); all sizes are powers of two
+            const uint32_t l_shift = P.unit_len == 1u ? 0u : RT_SEGMENT_SHIFT, k_shift = P.round_units_shift;
+            const uint32_t g_shift = 6u - l_shift - k_shift;                    // log2(pixels per round)
+            const uint32_t q = lane & ((1u << g_shift) - 1u), j = lane >> g_shift;
+            const uint32_t u_in = j >> l_shift, jj = j & (P.unit_len - 1u);
+            const uint32_t sub = blk_unit & ((1u << k_shift) - 1u), unit_local = ((blk_unit >> k_shift) << k_shift) + u_in;
             const uint32_t x0 = (blk_tile % P.tiles_x) * 8u, y0 = (blk_tile / P.tiles_x) * 8u;
-            const uint32_t sa = (P.unit_first + blk_unit) * Q, sb = sa + Q, r_end = P.sample_first + P.sample_count;
-            const uint32_t s_lo = sa > P.sample_first ? sa : P.sample_first, s_hi = sb < r_end ? sb : r_end;
-            // pixel (y * 8 + x within the tile) of this lane in pixel group g: the groups of a whole-segment
-            // unit are 4x2 pixels, which keeps the rays of a round closer together than a row of 8
-            auto group_pixel = [&](uint32_t g) -> uint32_t {
-                if (Q == 1u) return q;
-                return (((g >> 1) << 1) | (q >> 2)) * 8u + (((g & 1u) << 2) | (q & 3u));
+            const uint32_t s_mine = (P.unit_first + unit_local) * P.unit_len + jj;
+            const bool s_ok = s_mine >= P.sample_first && s_mine < P.sample_first + P.sample_count;
+            // pixel of this lane in round g: Z-order inside the tile, so that the pixels of a round and of a
+            // block form compact rectangles (8 -> 4x2, 4 -> 2x2, 2 -> 2x1)
+            auto round_pixel = [&](uint32_t g, uint32_t& x, uint32_t& y) {
+                const uint32_t z = (sub << (6u - k_shift)) + (g << g_shift) + q;
+                x = (z & 1u) | ((z >> 1) & 2u) | ((z >> 2) & 4u);
+                y = ((z >> 1) & 1u) | ((z >> 2) & 2u) | ((z >> 3) & 4u);
             };
             for (;;) {
                 if (round_next != 0u) {
-                    // close the round: segment sums of its pixels
+                    // close the round: segment sums of its pixels, ((0 + c0) + c1) + ... in sample order
                     const F3 c = s != RT_NONE ? sample_col : f3(0.0f, 0.0f, 0.0f);     // (x + 0 == x: the sum is never -0)
                     F3 sum = f3(0.0f, 0.0f, 0.0f);
-                    for (uint32_t jj = 0; jj < Q; jj++) {
-                        const int src = (int)(q + (jj << pg_shift));
+                    for (uint32_t k = 0; k < P.unit_len; k++) {
+                        const int src = (int)(((((u_in << l_shift) + k)) << g_shift) | q);
                         sum = sum + f3(__shfl(c.x, src, 64), __shfl(c.y, src, 64), __shfl(c.z, src, 64));
                     }
-                    const uint32_t within = group_pixel(round_next - 1u);
-                    if (j == 0u && x0 + (within & 7u) < P.cw && y0 + (within >> 3) < P.ch) {
-                        float* out = P.partial + ((uint64_t)(blk_unit * (P.pix_slots >> 6) + blk_tile) * 64u + within) * 3;     // one block = 768 contiguous bytes
+                    uint32_t x, y; round_pixel(round_next - 1u, x, y);
+                    if (jj == 0u && x0 + x < P.cw && y0 + y < P.ch) {
+                        float* out = P.partial + ((uint64_t)(unit_local * (P.pix_slots >> 6) + blk_tile) * 64u + (y * 8u + x)) * 3;
                         out[0] = sum.x; out[1] = sum.y; out[2] = sum.z;
                     }
                 }
-                if (round_next == Q) { state = NEED_BLOCK; break; }      // wait for the wave's next block
-                const uint32_t within = group_pixel(round_next);
+                if (round_next == P.unit_len) { state = NEED_BLOCK; break; }      // wait for the wave's next block
+                uint32_t x, y; round_pixel(round_next, x, y);
                 round_next++;
-                const uint32_t x = x0 + (within & 7u), y = y0 + (within >> 3);
-                s = (x < P.cw && y < P.ch && s_lo + j < s_hi) ? s_lo + j : RT_NONE;      // lanes off the chunk's edge sit the round out
+                x += x0; y += y0;
+                s = (x < P.cw && y < P.ch && s_ok) ? s_mine : RT_NONE;      // lanes off the chunk's edge sit the round out
                 if (s != RT_NONE) {
                     PH(PH_STAGE_C);
                     const uint32_t px = P.left + x;
@@ -1338,6 +1343,7 @@ int enqueue_accumulate(RtScene* scene, Workspace& ws, const RtSettings* st, cons
     uint32_t batch = (uint32_t)((1ull << 30) / ((uint64_t)pix_slots * 12ull * units_per_seg));
     if (batch == 0) batch = 1;
     if (batch > nseg) batch = nseg;
+    if (batch > 8) batch &= ~7u;              // (whole groups of units that share their rounds, see round_units_shift)
     int rc = ws.partial.ensure((size_t)batch * units_per_seg * pix_slots * 12);
     if (rc) return rc;
 
@@ -1373,6 +1379,11 @@ int enqueue_accumulate(RtScene* scene, Workspace& ws, const RtSettings* st, cons
         const uint32_t s_hi = (seg_lo + b0 + bn) * RT_SAMPLE_SEGMENT < sample_first + sample_count ? (seg_lo + b0 + bn) * RT_SAMPLE_SEGMENT
                                                                                                     : sample_first + sample_count;     // exclusive
         P.unit_first = s_lo / unit_len; P.unit_count = (s_hi - 1) / unit_len - P.unit_first + 1;
+        {
+            static const uint32_t max_shift = []() { const char* e = getenv("RT_ROUND_UNITS"); const int v = e ? atoi(e) : 8; return v >= 8 ? 3u : v >= 4 ? 2u : v >= 2 ? 1u : 0u; }();
+            P.round_units_shift = 0;
+            while (!fine && P.round_units_shift < max_shift && P.unit_count % (2u << P.round_units_shift) == 0) P.round_units_shift++;
+        }
         const uint64_t items = (uint64_t)P.pix_slots * P.unit_count;
         uint64_t blocks = (items + RT_BLOCK - 1) / RT_BLOCK;
         if (blocks > (uint64_t)scene->grid_blocks) blocks = scene->grid_blocks;
