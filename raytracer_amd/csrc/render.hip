@@ -1380,7 +1380,10 @@ int enqueue_accumulate(RtScene* scene, Workspace& ws, const RtSettings* st, cons
                                                                                                     : sample_first + sample_count;     // exclusive
         P.unit_first = s_lo / unit_len; P.unit_count = (s_hi - 1) / unit_len - P.unit_first + 1;
         {
-            static const uint32_t max_shift = []() { const char* e = getenv("RT_ROUND_UNITS"); const int v = e ? atoi(e) : 8; return v >= 8 ? 3u : v >= 4 ? 2u : v >= 2 ? 1u : 0u; }();
+            // up to 8 units share their rounds (64 samples of one pixel side by side); RT_ROUND_UNITS = 1 / 2 / 4 lowers the cap (experiments, tests)
+            const char* e = getenv("RT_ROUND_UNITS");
+            const int cap = e ? atoi(e) : 8;
+            const uint32_t max_shift = cap >= 8 ? 3u : cap >= 4 ? 2u : cap >= 2 ? 1u : 0u;
             P.round_units_shift = 0;
             while (!fine && P.round_units_shift < max_shift && P.unit_count % (2u << P.round_units_shift) == 0) P.round_units_shift++;
         }

@@ -14,6 +14,7 @@
 #include "scene_build.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 
@@ -405,7 +406,9 @@ int build_flat_scene(const RtSceneDesc* d, FlatScene& out, std::string& err) {
         ecent[i] = box_is_infinite(bx) ? origin
                                        : P3{bx.lo.x * 0.5f + bx.hi.x * 0.5f, bx.lo.y * 0.5f + bx.hi.y * 0.5f, bx.lo.z * 0.5f + bx.hi.z * 0.5f};
     }
+    const auto bt0 = std::chrono::steady_clock::now();
     Tree tlas = build_tree(ebox, ecent);
+    const auto bt1 = std::chrono::steady_clock::now();
 
     // ---- emit nodes -------------------------------------------------------------
     out.nodes.clear();
@@ -414,6 +417,8 @@ int build_flat_scene(const RtSceneDesc* d, FlatScene& out, std::string& err) {
     Tree tlas_walk;
     bool tlas_own = false;
     if (walk_trees) { tlas_walk = build_walk_tree(tlas); tlas_own = emitted_depth(tlas_walk) <= std::max(kMaxWalkDepth, emitted_depth(tlas)); }
+    const auto bt2 = std::chrono::steady_clock::now();
+    if (getenv("RT_BUILD_TIMING")) fprintf(stderr, "tlas: reference tree %.2f s, walk tree %.2f s\n", std::chrono::duration<double>(bt1 - bt0).count(), std::chrono::duration<double>(bt2 - bt1).count());
     Emitter te{out.nodes, 0, tlas_own ? tlas_walk : tlas};
     v.tlas_root_ref = te.emit(0, 0);
     put3(v.tlas_min, RtV3{tlas.nodes[0].box.lo.x, tlas.nodes[0].box.lo.y, tlas.nodes[0].box.lo.z});

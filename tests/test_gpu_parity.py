@@ -133,7 +133,7 @@ def test_image_independent_of_chunking():
     assert not np.array_equal(whole, other)
 
 
-@pytest.mark.parametrize("spp,first,count", [(16, 0, 16), (19, 0, 19), (40, 3, 30), (9, 8, 1)])
+@pytest.mark.parametrize("spp,first,count", [(16, 0, 16), (19, 0, 19), (40, 3, 30), (9, 8, 1), (64, 0, 64), (128, 32, 96)])
 def test_work_split_does_not_change_the_bits(spp, first, count, monkeypatch):
     """Under-filled launches deal single samples instead of 8-sample segments to the lanes; the segment sums are
     then formed by the fold kernel with the same additions, so both splits give identical bits."""
@@ -143,17 +143,21 @@ def test_work_split_does_not_change_the_bits(spp, first, count, monkeypatch):
     st, ch = RenderSettings(w, h, 6, spp), RenderChunk(0, 0, w, h)
     stream = torch.cuda.current_stream().cuda_stream
     out = {}
-    for split in ("0", "1"):
+    # whole-segment units with 1 / 2 / 4 / 8 units sharing a round (8 ... 64 samples of a pixel side by side in a
+    # wave), and one-sample units
+    for split, units in (("0", "8"), ("0", "4"), ("0", "2"), ("0", "1"), ("1", "8")):
         monkeypatch.setenv("RT_FINE_SPLIT", split)
+        monkeypatch.setenv("RT_ROUND_UNITS", units)
         acc = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda:0")
         cn = torch.zeros(4, dtype=torch.int64, device="cuda:0")
         scene.accumulate_chunk_device(st, ch, 21, first, count, acc.data_ptr(), cn.data_ptr(), stream)
         torch.cuda.synchronize()
-        out[split] = (acc.cpu().numpy(), cn.tolist())
-    assert np.array_equal(out["0"][0], out["1"][0]) and out["0"][1] == out["1"][1]
-    assert out["0"][1][3] == w * h * count
+        out[split + units] = (acc.cpu().numpy(), cn.tolist())
+    for key in out:
+        assert np.array_equal(out[key][0], out["08"][0]) and out[key][1] == out["08"][1], key
+    assert out["08"][1][3] == w * h * count
     ref = oracle.accumulate_chunk(st, ch, 21, first, count)
-    d = np.abs(out["1"][0] - ref)
+    d = np.abs(out["18"][0] - ref)
     assert (d.max(axis=2) > 1e-3).mean() < 2e-3 and d.mean() < 1e-4
 
 
