@@ -14,7 +14,9 @@
 #include "scene_build.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <thread>
 #include <cmath>
 #include <cstring>
 
@@ -66,19 +68,34 @@ Box range_box(const std::vector<Box>& boxes, const std::vector<uint32_t>& perm, 
     return b;
 }
 
-Tree build_tree(const std::vector<Box>& boxes, const std::vector<P3>& centroids) {
-    Tree t;
-    const uint32_t n = (uint32_t)boxes.size();
-    t.perm.resize(n);
-    for (uint32_t i = 0; i < n; i++) t.perm[i] = i;
-    t.nodes.reserve((size_t)n * 2);
-    t.nodes.push_back(TreeNode{range_box(boxes, t.perm, 0, n), 0, n, -1, -1});
-    std::vector<uint32_t> todo{0};
+// Large inputs (point clouds, big meshes) are built by several host threads: the top of the tree
+// serially, every subtree below kParallelGrain objects as a task of its own on a disjoint slice of
+// `perm`.  Subtrees are spliced in task order, so the result does not depend on the thread count.
+constexpr uint32_t kParallelMin = 200000, kParallelGrain = 32768;
+
+template <class Task, class Fn>
+void run_tasks(std::vector<Task>& tasks, Fn fn) {
+    const unsigned hw = std::thread::hardware_concurrency();
+    const unsigned n_threads = std::min<unsigned>({hw ? hw : 1u, 16u, (unsigned)tasks.size()});
+    std::atomic<size_t> next{0};
+    auto worker = [&]() { for (size_t i; (i = next.fetch_add(1)) < tasks.size();) fn(tasks[i]); };
+    std::vector<std::thread> pool;
+    for (unsigned k = 1; k < n_threads; k++) pool.emplace_back(worker);
+    worker();
+    for (std::thread& th : pool) th.join();
+}
+
+// bvh.rs:144-188 on the subtree of nodes[root] (children appended to `nodes`); nodes of at most
+// `defer_below` objects are left unsplit and reported in `deferred` instead (0: split everything).
+void subdivide_reference(std::vector<TreeNode>& nodes, uint32_t root, std::vector<uint32_t>& perm, const std::vector<Box>& boxes,
+                         const std::vector<P3>& centroids, uint32_t defer_below, std::vector<uint32_t>* deferred) {
+    std::vector<uint32_t> todo{root};
     while (!todo.empty()) {
         const uint32_t ni = todo.back(); todo.pop_back();
-        const uint32_t first = t.nodes[ni].first, count = t.nodes[ni].count;
+        const uint32_t first = nodes[ni].first, count = nodes[ni].count;
         if (count <= 2) continue;
-        uint32_t* idx = t.perm.data() + first;
+        if (count <= defer_below) { deferred->push_back(ni); continue; }
+        uint32_t* idx = perm.data() + first;
         // extent of the centroids -> longest axis (note: the comparisons use the signed
         // extent, only the remembered length is abs'ed - bvh.rs:118-127)
         Box cb{centroids[idx[0]], centroids[idx[0]]};
@@ -99,12 +116,44 @@ Tree build_tree(const std::vector<Box>& boxes, const std::vector<P3>& centroids)
         }
         const uint32_t left_len = i + 1, right_len = count - left_len;
         if (left_len == 0 || right_len == 0) continue;
-        const int32_t l = (int32_t)t.nodes.size();
-        t.nodes.push_back(TreeNode{range_box(boxes, t.perm, first, left_len), first, left_len, -1, -1});
-        t.nodes.push_back(TreeNode{range_box(boxes, t.perm, first + left_len, right_len), first + left_len, right_len, -1, -1});
-        t.nodes[ni].left = l; t.nodes[ni].right = l + 1;
+        const int32_t l = (int32_t)nodes.size();
+        nodes.push_back(TreeNode{range_box(boxes, perm, first, left_len), first, left_len, -1, -1});
+        nodes.push_back(TreeNode{range_box(boxes, perm, first + left_len, right_len), first + left_len, right_len, -1, -1});
+        nodes[ni].left = l; nodes[ni].right = l + 1;
         todo.push_back((uint32_t)l); todo.push_back((uint32_t)l + 1);
     }
+}
+
+// Appends a subtree built in its own vector (node 0 = the subtree's root, a copy of dst[at]) to dst.
+void splice_subtree(std::vector<TreeNode>& dst, uint32_t at, const std::vector<TreeNode>& sub) {
+    const int32_t shift = (int32_t)dst.size() - 1;            // sub node k (k >= 1) becomes dst node k + shift
+    dst[at] = sub[0];
+    if (sub[0].left >= 0) { dst[at].left += shift; dst[at].right += shift; }
+    for (size_t k = 1; k < sub.size(); k++) {
+        TreeNode n = sub[k];
+        if (n.left >= 0) { n.left += shift; n.right += shift; }
+        dst.push_back(n);
+    }
+}
+
+Tree build_tree(const std::vector<Box>& boxes, const std::vector<P3>& centroids) {
+    Tree t;
+    const uint32_t n = (uint32_t)boxes.size();
+    t.perm.resize(n);
+    for (uint32_t i = 0; i < n; i++) t.perm[i] = i;
+    t.nodes.reserve((size_t)n * 2);
+    t.nodes.push_back(TreeNode{range_box(boxes, t.perm, 0, n), 0, n, -1, -1});
+    if (n < kParallelMin) { subdivide_reference(t.nodes, 0, t.perm, boxes, centroids, 0, nullptr); return t; }
+    struct Task { uint32_t node; std::vector<TreeNode> sub; };
+    std::vector<uint32_t> deferred;
+    subdivide_reference(t.nodes, 0, t.perm, boxes, centroids, kParallelGrain, &deferred);
+    std::vector<Task> tasks(deferred.size());
+    for (size_t k = 0; k < deferred.size(); k++) tasks[k].node = deferred[k];
+    run_tasks(tasks, [&](Task& task) {
+        task.sub.push_back(t.nodes[task.node]);
+        subdivide_reference(task.sub, 0, t.perm, boxes, centroids, 0, nullptr);      // (its slice of perm is this task's alone)
+    });
+    for (const Task& task : tasks) splice_subtree(t.nodes, task.node, task.sub);
     return t;
 }
 
@@ -187,33 +236,23 @@ double half_area(const double lo[3], const double hi[3]) {
     return dx * dy + dy * dz + dz * dx;
 }
 
-Tree build_walk_tree(const Tree& ref) {
-    std::vector<LeafRec> leaves;
-    for (const TreeNode& n : ref.nodes) if (n.left < 0) leaves.push_back(LeafRec{n.box, n.first, n.count});
-    Tree t;
-    const uint32_t n_leaves = (uint32_t)leaves.size();
-    std::vector<uint32_t> ids(n_leaves);
-    for (uint32_t i = 0; i < n_leaves; i++) ids[i] = i;
-    std::vector<double> cen((size_t)n_leaves * 3);
-    for (uint32_t i = 0; i < n_leaves; i++) {
-        const Box& b = leaves[i].box;
-        cen[3 * i] = 0.5 * (clamp30(b.lo.x) + clamp30(b.hi.x)); cen[3 * i + 1] = 0.5 * (clamp30(b.lo.y) + clamp30(b.hi.y));
-        cen[3 * i + 2] = 0.5 * (clamp30(b.lo.z) + clamp30(b.hi.z));
-    }
-    t.nodes.reserve((size_t)n_leaves * 2);
-    struct Job { uint32_t node, lo, hi; };
-    std::vector<Job> todo;
-    t.nodes.push_back(TreeNode{Box{}, 0, 0, -1, -1});
-    todo.push_back(Job{0, 0, n_leaves});
+struct WalkJob { uint32_t node, lo, hi; };
+
+// Splits the leaf range of every job reachable from `root_job` (children appended to `nodes`); ranges of at
+// most `defer_below` leaves are reported in `deferred` instead (0: split everything).
+void subdivide_walk(std::vector<TreeNode>& nodes, WalkJob root_job, const std::vector<LeafRec>& leaves, std::vector<uint32_t>& ids,
+                    const std::vector<double>& cen, uint32_t defer_below, std::vector<WalkJob>* deferred) {
     constexpr int BINS = RT_SAH_BINS;
+    std::vector<WalkJob> todo{root_job};
     while (!todo.empty()) {
-        const Job j = todo.back(); todo.pop_back();
+        const WalkJob j = todo.back(); todo.pop_back();
         const uint32_t n = j.hi - j.lo;
+        if (n > 1 && n <= defer_below) { deferred->push_back(j); continue; }
         // exact union of the leaf boxes of the range
         Box bx = leaves[ids[j.lo]].box;
         for (uint32_t k = j.lo + 1; k < j.hi; k++) { grow(bx, leaves[ids[k]].box.lo); grow(bx, leaves[ids[k]].box.hi); }
-        t.nodes[j.node].box = bx;
-        if (n == 1) { const LeafRec& l = leaves[ids[j.lo]]; t.nodes[j.node].first = l.first; t.nodes[j.node].count = l.count; continue; }
+        nodes[j.node].box = bx;
+        if (n == 1) { const LeafRec& l = leaves[ids[j.lo]]; nodes[j.node].first = l.first; nodes[j.node].count = l.count; continue; }
         // binned SAH on the centroids
         double cb_lo[3] = {1e300, 1e300, 1e300}, cb_hi[3] = {-1e300, -1e300, -1e300};
         for (uint32_t k = j.lo; k < j.hi; k++) for (int a = 0; a < 3; a++) {
@@ -260,13 +299,41 @@ Tree build_walk_tree(const Tree& ref) {
             const uint32_t pm = (uint32_t)(m - ids.data());
             if (pm > j.lo && pm < j.hi) mid = pm;
         }
-        const int32_t l = (int32_t)t.nodes.size();
-        t.nodes.push_back(TreeNode{Box{}, 0, 0, -1, -1});
-        t.nodes.push_back(TreeNode{Box{}, 0, 0, -1, -1});
-        t.nodes[j.node].left = l; t.nodes[j.node].right = l + 1;
-        todo.push_back(Job{(uint32_t)l, j.lo, mid});
-        todo.push_back(Job{(uint32_t)l + 1, mid, j.hi});
+        const int32_t l = (int32_t)nodes.size();
+        nodes.push_back(TreeNode{Box{}, 0, 0, -1, -1});
+        nodes.push_back(TreeNode{Box{}, 0, 0, -1, -1});
+        nodes[j.node].left = l; nodes[j.node].right = l + 1;
+        todo.push_back(WalkJob{(uint32_t)l, j.lo, mid});
+        todo.push_back(WalkJob{(uint32_t)l + 1, mid, j.hi});
     }
+}
+
+Tree build_walk_tree(const Tree& ref) {
+    std::vector<LeafRec> leaves;
+    for (const TreeNode& n : ref.nodes) if (n.left < 0) leaves.push_back(LeafRec{n.box, n.first, n.count});
+    Tree t;
+    const uint32_t n_leaves = (uint32_t)leaves.size();
+    std::vector<uint32_t> ids(n_leaves);
+    for (uint32_t i = 0; i < n_leaves; i++) ids[i] = i;
+    std::vector<double> cen((size_t)n_leaves * 3);
+    for (uint32_t i = 0; i < n_leaves; i++) {
+        const Box& b = leaves[i].box;
+        cen[3 * i] = 0.5 * (clamp30(b.lo.x) + clamp30(b.hi.x)); cen[3 * i + 1] = 0.5 * (clamp30(b.lo.y) + clamp30(b.hi.y));
+        cen[3 * i + 2] = 0.5 * (clamp30(b.lo.z) + clamp30(b.hi.z));
+    }
+    t.nodes.reserve((size_t)n_leaves * 2);
+    t.nodes.push_back(TreeNode{Box{}, 0, 0, -1, -1});
+    if (n_leaves < kParallelMin) { subdivide_walk(t.nodes, WalkJob{0, 0, n_leaves}, leaves, ids, cen, 0, nullptr); return t; }
+    struct Task { WalkJob job; std::vector<TreeNode> sub; };
+    std::vector<WalkJob> deferred;
+    subdivide_walk(t.nodes, WalkJob{0, 0, n_leaves}, leaves, ids, cen, kParallelGrain, &deferred);
+    std::vector<Task> tasks(deferred.size());
+    for (size_t k = 0; k < deferred.size(); k++) tasks[k].job = deferred[k];
+    run_tasks(tasks, [&](Task& task) {
+        task.sub.push_back(TreeNode{Box{}, 0, 0, -1, -1});
+        subdivide_walk(task.sub, WalkJob{0, task.job.lo, task.job.hi}, leaves, ids, cen, 0, nullptr);      // (its slice of ids is this task's alone)
+    });
+    for (const Task& task : tasks) splice_subtree(t.nodes, task.job.node, task.sub);
     return t;
 }
 
@@ -348,6 +415,14 @@ int build_flat_scene(const RtSceneDesc* d, FlatScene& out, std::string& err) {
         if (e.translation_count > 255 || e.rotation_count > 255) { err = "entity: more than 255 transforms"; return RT_E_LIMIT; }
     }
 
+    const bool timing = getenv("RT_BUILD_TIMING") != nullptr;
+    auto lap_t = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        const auto now = std::chrono::steady_clock::now();
+        if (timing) fprintf(stderr, "scene build: %-28s %.3f s\n", what, std::chrono::duration<double>(now - lap_t).count());
+        lap_t = now;
+    };
+    lap("validation");
     // ---- camera / scalars -----------------------------------------------------
     DevSceneView& v = out.view;
     auto put3 = [](float* dst, const RtV3& s) { dst[0] = s.x; dst[1] = s.y; dst[2] = s.z; };
@@ -406,9 +481,9 @@ int build_flat_scene(const RtSceneDesc* d, FlatScene& out, std::string& err) {
         ecent[i] = box_is_infinite(bx) ? origin
                                        : P3{bx.lo.x * 0.5f + bx.hi.x * 0.5f, bx.lo.y * 0.5f + bx.hi.y * 0.5f, bx.lo.z * 0.5f + bx.hi.z * 0.5f};
     }
-    const auto bt0 = std::chrono::steady_clock::now();
+    lap("BLAS trees, entity boxes");
     Tree tlas = build_tree(ebox, ecent);
-    const auto bt1 = std::chrono::steady_clock::now();
+    lap("TLAS reference tree");
 
     // ---- emit nodes -------------------------------------------------------------
     out.nodes.clear();
@@ -417,8 +492,7 @@ int build_flat_scene(const RtSceneDesc* d, FlatScene& out, std::string& err) {
     Tree tlas_walk;
     bool tlas_own = false;
     if (walk_trees) { tlas_walk = build_walk_tree(tlas); tlas_own = emitted_depth(tlas_walk) <= std::max(kMaxWalkDepth, emitted_depth(tlas)); }
-    const auto bt2 = std::chrono::steady_clock::now();
-    if (getenv("RT_BUILD_TIMING")) fprintf(stderr, "tlas: reference tree %.2f s, walk tree %.2f s\n", std::chrono::duration<double>(bt1 - bt0).count(), std::chrono::duration<double>(bt2 - bt1).count());
+    lap("TLAS walk tree");
     Emitter te{out.nodes, 0, tlas_own ? tlas_walk : tlas};
     v.tlas_root_ref = te.emit(0, 0);
     put3(v.tlas_min, RtV3{tlas.nodes[0].box.lo.x, tlas.nodes[0].box.lo.y, tlas.nodes[0].box.lo.z});
@@ -426,6 +500,7 @@ int build_flat_scene(const RtSceneDesc* d, FlatScene& out, std::string& err) {
     out.info.tlas_node_count = out.nodes.size();
     out.info.tlas_depth = emitted_depth(tlas);             // of the reference-shaped tree
     const uint32_t tlas_walk_depth = te.depth;
+    lap("TLAS nodes");
 
     out.meshes.resize(n_mesh);
     out.blas_order.resize(n_mesh);
@@ -479,6 +554,7 @@ int build_flat_scene(const RtSceneDesc* d, FlatScene& out, std::string& err) {
     out.info.triangle_count = tri_total;
     out.info.entity_count = n_ent;
 
+    lap("BLAS walk trees, nodes, triangles");
     // ---- entities in TLAS leaf order ------------------------------------------
     emission_positions(tlas, pos_order);
     std::vector<uint32_t> erank(n_ent);
@@ -527,6 +603,7 @@ int build_flat_scene(const RtSceneDesc* d, FlatScene& out, std::string& err) {
     out.info.instanced_triangle_count = inst_tris;
     if (out.xforms.empty()) out.xforms.emplace_back();
 
+    lap("entity records");
     // ---- planes / materials / textures / lights ---------------------------------
     out.planes.resize(d->plane_count ? d->plane_count : 1);
     for (uint64_t i = 0; i < d->plane_count; i++) {
@@ -573,6 +650,7 @@ int build_flat_scene(const RtSceneDesc* d, FlatScene& out, std::string& err) {
     // traversal stack: one deferred sibling per inner level of the TLAS, one
     // TLAS-leaf continuation, one per inner level of the deepest BLAS, + margin
     v.stack_entries = tlas_walk_depth + 1 + blas_walk_depth + 2;
+    lap("materials, textures, lights");
     return RT_OK;
 }
 

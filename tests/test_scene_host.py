@@ -141,6 +141,18 @@ def test_bvh_build_matches_oracle(name):
     assert info.triangle_count == sum(d.meshes[m].tri_count for m in range(d.mesh_count))
 
 
+def test_large_scene_is_built_by_several_threads_in_the_reference_order():
+    """From 200 000 objects on, subtrees are built by a pool of host threads; the order (and with it every
+    exact tie) is still the reference's, and does not depend on how many threads there are."""
+    b = SceneBuilder.sample("Point Cloud", CameraConfiguration(64, 36), params={"Cloud Point Count": 300000})
+    host, orc = Scene(b, device=-1), OracleScene(b)
+    order = host.bvh_order()
+    assert np.array_equal(order, orc.bvh_order())
+    assert host.info().tlas_depth == orc.bvh_depth() - 1
+    again = Scene(b, device=-1)
+    assert np.array_equal(again.bvh_order(), order) and again.info().tlas_node_count == host.info().tlas_node_count
+
+
 def test_degenerate_leaf_is_split_without_losing_objects():
     # 40 identical spheres: every split leaves one side empty (bvh.rs:169), the reference
     # keeps one 40-object leaf; the product splits it into <= 8-object leaves with equal boxes
