@@ -133,12 +133,12 @@ def test_image_independent_of_chunking():
     assert not np.array_equal(whole, other)
 
 
-@pytest.mark.parametrize("spp,first,count", [(16, 0, 16), (19, 0, 19), (40, 3, 30), (9, 8, 1), (64, 0, 64), (128, 32, 96)])
-def test_work_split_does_not_change_the_bits(spp, first, count, monkeypatch):
+@pytest.mark.parametrize("spp,first,count,w,h", [(16, 0, 16, 72, 40), (19, 0, 19, 72, 40), (40, 3, 30, 72, 40), (9, 8, 1, 72, 40),
+                                                 (64, 0, 64, 72, 40), (128, 32, 96, 72, 40), (64, 0, 64, 53, 29), (136, 8, 128, 13, 11)])
+def test_work_split_does_not_change_the_bits(spp, first, count, w, h, monkeypatch):
     """Under-filled launches deal single samples instead of 8-sample segments to the lanes; the segment sums are
     then formed by the fold kernel with the same additions, so both splits give identical bits."""
     import torch
-    w, h = 72, 40
     b, scene, oracle = make("Random Spheres", w, h)
     st, ch = RenderSettings(w, h, 6, spp), RenderChunk(0, 0, w, h)
     stream = torch.cuda.current_stream().cuda_stream
