@@ -25,7 +25,7 @@ struct alignas(16) Word4 {
 // measured slower than scalar on gfx950 - see slab2 in render.hip):
 //   w0 = (lmin.x rmin.x lmin.y rmin.y)   w1 = (lmin.z rmin.z lmax.x rmax.x)
 //   w2 = (lmax.y rmax.y lmax.z rmax.z)   w3.u = (left ref, right ref, -, -)
-// child ref: bit31 = 0 -> inner node index (relative to the BVH's node base)
+// child ref: bit31 = 0 -> inner node: index in the scene's one node array
 //            bit31 = 1 -> leaf: bits 28..30 = count-1 (1..8), bits 0..27 = first
 //                        object position (relative to the BVH's object base)
 struct alignas(64) DevNode { Word4 w[4]; };
@@ -34,6 +34,14 @@ struct alignas(64) DevNode { Word4 w[4]; };
 #define RT_REF_COUNT_SHIFT 28
 #define RT_REF_FIRST_MASK 0x0FFFFFFFu
 #define RT_LEAF_MAX       8u
+
+// Threads of a render block, and the LDS node cache of a block: the scene's first `lds_nodes` records,
+// RT_NODE_CACHE_STRIDE bytes apart (20 dwords: eight different records fall into eight different groups
+// of four banks, where 64-byte spacing would put all of them into two).
+#ifndef RT_BLOCK
+#define RT_BLOCK 256
+#endif
+#define RT_NODE_CACHE_STRIDE 80u
 
 // ---- Entity (implementation.rs:224-230), stored in TLAS leaf order ----------
 // w0.f = (t0.x t0.y t0.z radius)  first translation inline (common case: 1)
@@ -87,7 +95,8 @@ struct DevSceneView {
     uint32_t mesh_entities;       // some entity is a mesh instance (the walk enters BLASes)
     uint32_t loose_boxes;         // some entity rotates about a non-unit axis: its box does not bound its hits, so
                                   // TLAS boxes are tested against the ray's whole interval like the reference does
-    const DevNode* nodes;         // TLAS nodes first, then every BLAS
+    uint32_t lds_nodes;           // the first lds_nodes node records are kept in LDS by the render kernel
+    const DevNode* nodes;         // the top levels of the TLAS and of every BLAS first (breadth first), then the rest of each tree (depth first)
     const DevEntity* entities;    // TLAS leaf order
     const Word4* xforms;
     const DevMesh* meshes;

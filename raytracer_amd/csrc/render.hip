@@ -49,9 +49,6 @@
 // shorten the tail of a launch, larger ones amortise the per-item set-up).
 #define RT_SEGMENT_SHIFT 3u
 #define RT_SAMPLE_SEGMENT (1u << RT_SEGMENT_SHIFT)
-#ifndef RT_BLOCK
-#define RT_BLOCK 256
-#endif
 #define RT_PENDING_MAX 8
 #ifndef RT_QUEUES
 #define RT_QUEUES 16u            /* block counters per launch, one cache line each */
@@ -210,13 +207,13 @@ __device__ __forceinline__ void trace(const DevSceneView& S, const F3 wo, const 
 
     F3 o = wo, d = wd, inv = f3(1.0f / wd.x, 1.0f / wd.y, 1.0f / wd.z);
     uint32_t sp = 0, inst_sp = RT_NONE;    // inst_sp != NONE: inside a BLAS entered at that stack height
-    const DevNode* nodes = S.nodes;        // current BVH's node base
+    const DevNode* const nodes = S.nodes;  // TLAS and every BLAS: child refs index the one array
     uint32_t tri_base = 0;                 // current BLAS
     uint32_t cur_ent = 0, cur_erank = 0;
 
     // next deferred subtree; leaving a BLAS restores the world-space ray
     auto pop = [&]() -> uint32_t {
-        if (sp == inst_sp) { inst_sp = RT_NONE; o = wo; d = wd; inv = f3(1.0f / wd.x, 1.0f / wd.y, 1.0f / wd.z); nodes = S.nodes; }
+        if (sp == inst_sp) { inst_sp = RT_NONE; o = wo; d = wd; inv = f3(1.0f / wd.x, 1.0f / wd.y, 1.0f / wd.z); }
         if (sp == 0) return RT_NONE;
         return stack[(--sp) * RT_BLOCK];
     };
@@ -325,7 +322,7 @@ __device__ __forceinline__ void trace(const DevSceneView& S, const F3 wo, const 
                         stack[(sp++) * RT_BLOCK] = RT_REF_LEAF_BIT | ((count - k - 2) << RT_REF_COUNT_SHIFT) | (ei + 1);
                     inst_sp = sp;
                     o = eo; d = ed; inv = einv;
-                    nodes = S.nodes + m0.u[0]; tri_base = m0.u[1];
+                    tri_base = m0.u[1];
                     cur_ent = ei; cur_erank = ldw(ew + 2).u[3];
                     cur = m0.u[3];
                     entered = true;
@@ -612,7 +609,17 @@ render_kernel(const DevSceneView S, const RenderParams P) {
     float t_min = 0.0f, t_max = 0.0f, best_t = 0.0f;
     Hit best; best.t = 0.0f; best.ent = RT_NONE; best.tri = RT_NONE; best.erank = 0;
     uint32_t cur = RT_NONE, sp = 0, inst_sp = RT_NONE, tri_base = 0, cur_ent = 0, cur_erank = 0;
-    const DevNode* nodes = S.nodes;
+
+    // Node cache: the scene's first S.lds_nodes records (the top levels of the TLAS and of every BLAS,
+    // scene_build.cpp) are read from LDS instead of through the vector memory path: the texture
+    // addresser is 70-80 % busy with the gathers of this kernel (18 cycles per wave instruction), and
+    // every ray walks the top levels (weekend +6 %).
+    uint32_t* const node_cache = lds_stack + (stack_cap + 3u) * RT_BLOCK;
+    for (uint32_t i = threadIdx.x; i < S.lds_nodes * 4u; i += RT_BLOCK) {
+        const float4 v = *reinterpret_cast<const float4*>(&S.nodes[i >> 2].w[i & 3u]);
+        *reinterpret_cast<float4*>(node_cache + (i >> 2) * (RT_NODE_CACHE_STRIDE / 4u) + (i & 3u) * 4u) = v;
+    }
+    __syncthreads();
 
     for (;;) {
         PH(PH_OUTER);
@@ -873,7 +880,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                 }
                 t_min = shadow ? closest : RT_BIAS; t_max = shadow ? l_t : RT_F32_MAX;
                 best.t = t_max; best.ent = RT_NONE; best.tri = RT_NONE; best.erank = 0; best_t = t_max;
-                sp = 0; inst_sp = RT_NONE; nodes = S.nodes;
+                sp = 0; inst_sp = RT_NONE;
                 float e;
                 cur = slab(S.tlas_min[0], S.tlas_min[1], S.tlas_min[2], S.tlas_max[0], S.tlas_max[1], S.tlas_max[2], o, inv, t_min, best_t, e)
                           ? S.tlas_root_ref : RT_NONE;
@@ -887,7 +894,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
         auto pop = [&]() -> uint32_t {
             if (sp == inst_sp) {
                 PH(PH_POP_INST);
-                inst_sp = RT_NONE; nodes = S.nodes;
+                inst_sp = RT_NONE;
                 const bool shadow = state == SHADOW;
                 o = shadow ? hp : ro; d = shadow ? -ldir : rd;
                 // the world-space reciprocals were parked in this lane's LDS column at the start of the ray
@@ -904,8 +911,16 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                 // the leaf bit set and ends the walk too).  One 64-byte record = two boxes.
                 while (cur < RT_REF_LEAF_BIT) {
                     PH(PH_NODE);
-                    const Word4* n = nodes[cur].w;
-                    const Word4 na = ldw(n), nb = ldw(n + 1), nc = ldw(n + 2), nr = ldw(n + 3);
+                    Word4 na, nb, nc, nr;
+                    if (cur < S.lds_nodes) {
+                        const float4* c = reinterpret_cast<const float4*>(node_cache + cur * (RT_NODE_CACHE_STRIDE / 4u));
+                        const float4 v0 = c[0], v1 = c[1], v2 = c[2], v3 = c[3];
+                        na.f[0] = v0.x; na.f[1] = v0.y; na.f[2] = v0.z; na.f[3] = v0.w; nb.f[0] = v1.x; nb.f[1] = v1.y; nb.f[2] = v1.z; nb.f[3] = v1.w;
+                        nc.f[0] = v2.x; nc.f[1] = v2.y; nc.f[2] = v2.z; nc.f[3] = v2.w; nr.f[0] = v3.x; nr.f[1] = v3.y; nr.f[2] = v3.z; nr.f[3] = v3.w;
+                    } else {
+                        const Word4* n = S.nodes[cur].w;
+                        na = ldw(n); nb = ldw(n + 1); nc = ldw(n + 2); nr = ldw(n + 3);
+                    }
                     float el, er; bool hl, hr;
                     slab2(na, nb, nc, o, inv, t_min, (LOOSE && inst_sp == RT_NONE) ? t_max : best_t, hl, hr, el, er);
                     if (hl && hr) {
@@ -1003,7 +1018,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                                         stack[(sp++) * RT_BLOCK] = RT_REF_LEAF_BIT | ((count - k - 2) << RT_REF_COUNT_SHIFT) | (ei + 1);
                                     inst_sp = sp;
                                     o = eo; d = ed; inv = einv;
-                                    nodes = S.nodes + m0.u[0]; tri_base = m0.u[1];
+                                    tri_base = m0.u[1];
                                     cur_ent = ei; cur_erank = ldw(ew + 2).u[3];
                                     cur = m0.u[3];
                                     entered = true;
@@ -1250,7 +1265,7 @@ struct RtScene {
     std::vector<Workspace*> pool_free;
     std::atomic<int> host_calls_in_flight{0};
     int grid_blocks = 0;
-    size_t lds_bytes = 0;
+    size_t lds_bytes = 0, stack_lds_bytes = 0;
     std::mutex profile_lock;
     bool profiling = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> profile_events;
@@ -1365,7 +1380,7 @@ int enqueue_accumulate(RtScene* scene, Workspace& ws, const RtSettings* st, cons
     if (!fine && order_tiles && n_tiles >= 256) {
         if ((rc = ws.order.ensure((size_t)n_tiles * 8 + 16))) return rc;
         uint32_t* tile_bin = (uint32_t*)ws.order.p; uint32_t* tile_order = tile_bin + n_tiles + 4;      // [-1] = expensive-tile count
-        hipLaunchKernelGGL(classify_kernel, dim3((n_tiles * 16 + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), scene->lds_bytes, stream, scene->view, P,
+        hipLaunchKernelGGL(classify_kernel, dim3((n_tiles * 16 + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), scene->stack_lds_bytes, stream, scene->view, P,
                            n_tiles, tile_bin);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t*)tile_bin, n_tiles, tile_order);
@@ -1468,7 +1483,9 @@ RtScene* rt_scene_create(const RtSceneDesc* desc, int device) {
         return fail();
     // launch shape: a resident grid (persistent lanes stride over the work items)
     s->lds_bytes = ((size_t)s->view.stack_entries + 3) * RT_BLOCK * sizeof(uint32_t);      // + 3 rows: parked world-space 1/d
-    if (s->lds_bytes > 64 * 1024) { set_error(RT_E_DEPTH, "BVH too deep for the LDS traversal stack (more than 64 levels)"); return fail(); }
+    s->stack_lds_bytes = s->lds_bytes;
+    s->lds_bytes += (size_t)s->view.lds_nodes * RT_NODE_CACHE_STRIDE;      // the node cache (sized by scene_build.cpp to fit four blocks per CU)
+    if (s->stack_lds_bytes > 64 * 1024) { set_error(RT_E_DEPTH, "BVH too deep for the LDS traversal stack (more than 64 levels)"); return fail(); }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { set_error(RT_E_HIP, "hipGetDeviceProperties failed"); return fail(); }
     int per_cu = 0;
@@ -1607,7 +1624,7 @@ int rt_primary_hits(RtScene* scene, const RtSettings* st, const RtRenderChunk* c
     RenderParams P{};
     P.width = st->width; P.height = st->height; P.max_reflections = st->max_reflections; P.spp = 1;
     P.left = ch->left; P.top = ch->top; P.cw = ch->width; P.ch = ch->height;
-    hipLaunchKernelGGL(primary_kernel, dim3((uint32_t)((npix + RT_BLOCK - 1) / RT_BLOCK)), dim3(RT_BLOCK), scene->lds_bytes, ws.stream,
+    hipLaunchKernelGGL(primary_kernel, dim3((uint32_t)((npix + RT_BLOCK - 1) / RT_BLOCK)), dim3(RT_BLOCK), scene->stack_lds_bytes, ws.stream,
                        scene->view, P, d_t, d_n, d_e, d_tri);
     HIP_TRY(hipGetLastError());
     if (t_out) HIP_TRY(hipMemcpyAsync(t_out, d_t, npix * 4, hipMemcpyDeviceToHost, ws.stream));

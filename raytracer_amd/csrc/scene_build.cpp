@@ -19,6 +19,7 @@
 #include <thread>
 #include <cmath>
 #include <cstring>
+#include <memory>
 
 namespace {
 
@@ -172,15 +173,23 @@ void emission_positions(const Tree& t, std::vector<uint32_t>& out) {
 // ---------------------------------------------------------------------------
 // Emit 64-byte two-box nodes
 // ---------------------------------------------------------------------------
+constexpr uint32_t RT_NONE_U32 = 0xFFFFFFFFu;
+
 struct Emitter {
-    std::vector<DevNode>& nodes;
-    uint32_t base;           // index of this BVH's first node in `nodes`
     const Tree& t;
     uint32_t depth = 0;      // max inner nodes on a root-to-leaf path
+
+    // the tree as it will be emitted: one record per inner node, children = leaf refs or records
+    struct ENode { Box lb, rb; uint32_t l, r; bool l_inner, r_inner; };
+    std::vector<ENode> en;
+    uint32_t root = 0; bool root_inner = false;
+
+    explicit Emitter(const Tree& tree) : t(tree) { root = build(0, 0, root_inner); }
 
     static uint32_t leaf_ref(uint32_t first, uint32_t count) {
         return RT_REF_LEAF_BIT | ((count - 1) << RT_REF_COUNT_SHIFT) | (first & RT_REF_FIRST_MASK);
     }
+    // one 16-byte word per axis pair - see device_scene.h
     static void put_boxes(DevNode& d, const Box& l, const Box& r) {
         d.w[0].f[0] = l.lo.x; d.w[0].f[1] = r.lo.x; d.w[0].f[2] = l.lo.y; d.w[0].f[3] = r.lo.y;
         d.w[1].f[0] = l.lo.z; d.w[1].f[1] = r.lo.z; d.w[1].f[2] = l.hi.x; d.w[1].f[3] = r.hi.x;
@@ -189,26 +198,59 @@ struct Emitter {
     // A leaf of more than RT_LEAF_MAX objects (only when a split left one side
     // empty, bvh.rs:169) becomes a small subtree whose boxes all equal the leaf's
     // box: every object is still tested exactly when that box is hit.
-    uint32_t emit_leaf(uint32_t first, uint32_t count, const Box& box, uint32_t level) {
-        if (count <= RT_LEAF_MAX) { if (level > depth) depth = level; return leaf_ref(first, count); }
-        const uint32_t me = (uint32_t)nodes.size(); nodes.emplace_back();
+    uint32_t build_leaf(uint32_t first, uint32_t count, const Box& box, uint32_t level, bool& inner) {
+        if (count <= RT_LEAF_MAX) { if (level > depth) depth = level; inner = false; return leaf_ref(first, count); }
+        const uint32_t me = (uint32_t)en.size(); en.emplace_back();
         const uint32_t half = count / 2;
-        const uint32_t l = emit_leaf(first, half, box, level + 1);
-        const uint32_t r = emit_leaf(first + half, count - half, box, level + 1);
-        DevNode& d = nodes[me];
-        put_boxes(d, box, box); d.w[3].u[0] = l; d.w[3].u[1] = r; d.w[3].u[2] = d.w[3].u[3] = 0;
-        return me - base;
+        bool li, ri;
+        const uint32_t l = build_leaf(first, half, box, level + 1, li);
+        const uint32_t r = build_leaf(first + half, count - half, box, level + 1, ri);
+        en[me] = ENode{box, box, l, r, li, ri};
+        inner = true;
+        return me;
     }
-    uint32_t emit(int32_t ni, uint32_t level) {
+    uint32_t build(int32_t ni, uint32_t level, bool& inner) {
         const TreeNode n = t.nodes[ni];
-        if (n.left < 0) return emit_leaf(n.first, n.count, n.box, level);
-        const uint32_t me = (uint32_t)nodes.size(); nodes.emplace_back();
-        const uint32_t l = emit(n.left, level + 1);
-        const uint32_t r = emit(n.right, level + 1);
-        DevNode& d = nodes[me];
-        put_boxes(d, t.nodes[n.left].box, t.nodes[n.right].box);
-        d.w[3].u[0] = l; d.w[3].u[1] = r; d.w[3].u[2] = d.w[3].u[3] = 0;
-        return me - base;
+        if (n.left < 0) return build_leaf(n.first, n.count, n.box, level, inner);
+        const uint32_t me = (uint32_t)en.size(); en.emplace_back();
+        bool li, ri;
+        const uint32_t l = build(n.left, level + 1, li);
+        const uint32_t r = build(n.right, level + 1, ri);
+        en[me] = ENode{t.nodes[n.left].box, t.nodes[n.right].box, l, r, li, ri};
+        inner = true;
+        return me;
+    }
+    // Writes the records into `nodes` (the scene's one node array; child refs are indices in it):
+    // the first `n_hot` records in breadth-first order - the top levels, which every ray visits and the
+    // render kernel keeps in LDS - from nodes[hot_base] on, the others depth first (a child next to its
+    // parent) from nodes[cold_base] on.  Returns the ref of the root.
+    uint32_t write(std::vector<DevNode>& nodes, uint32_t hot_base, uint32_t n_hot, uint32_t cold_base) {
+        if (!root_inner) return root;
+        std::vector<uint32_t> number(en.size(), RT_NONE_U32);
+        std::vector<uint32_t> order{root};
+        for (size_t i = 0; i < order.size() && i < n_hot; i++) {
+            const ENode& e = en[order[i]];
+            number[order[i]] = hot_base + (uint32_t)i;
+            if (e.l_inner) order.push_back(e.l);
+            if (e.r_inner) order.push_back(e.r);
+        }
+        uint32_t next_cold = cold_base;
+        std::vector<uint32_t> st{root};
+        while (!st.empty()) {
+            const uint32_t k = st.back(); st.pop_back();
+            if (number[k] == RT_NONE_U32) number[k] = next_cold++;
+            if (en[k].r_inner) st.push_back(en[k].r);
+            if (en[k].l_inner) st.push_back(en[k].l);
+        }
+        for (size_t k = 0; k < en.size(); k++) {
+            const ENode& e = en[k];
+            DevNode& d = nodes[number[k]];
+            put_boxes(d, e.lb, e.rb);
+            d.w[3].u[0] = e.l_inner ? number[e.l] : e.l;
+            d.w[3].u[1] = e.r_inner ? number[e.r] : e.r;
+            d.w[3].u[2] = d.w[3].u[3] = 0;
+        }
+        return number[root];
     }
 };
 
@@ -493,13 +535,15 @@ int build_flat_scene(const RtSceneDesc* d, FlatScene& out, std::string& err) {
     bool tlas_own = false;
     if (walk_trees) { tlas_walk = build_walk_tree(tlas); tlas_own = emitted_depth(tlas_walk) <= std::max(kMaxWalkDepth, emitted_depth(tlas)); }
     lap("TLAS walk tree");
-    Emitter te{out.nodes, 0, tlas_own ? tlas_walk : tlas};
-    v.tlas_root_ref = te.emit(0, 0);
+    // every tree as it will be emitted; the records are written once the LDS budget of the node cache is known
+    std::vector<std::unique_ptr<Emitter>> emitters;
+    emitters.emplace_back(new Emitter(tlas_own ? tlas_walk : tlas));
     put3(v.tlas_min, RtV3{tlas.nodes[0].box.lo.x, tlas.nodes[0].box.lo.y, tlas.nodes[0].box.lo.z});
     put3(v.tlas_max, RtV3{tlas.nodes[0].box.hi.x, tlas.nodes[0].box.hi.y, tlas.nodes[0].box.hi.z});
-    out.info.tlas_node_count = out.nodes.size();
+    out.info.tlas_node_count = emitters[0]->en.size();
     out.info.tlas_depth = emitted_depth(tlas);             // of the reference-shaped tree
-    const uint32_t tlas_walk_depth = te.depth;
+    const uint32_t tlas_walk_depth = emitters[0]->depth;
+    tlas_walk = Tree();
     lap("TLAS nodes");
 
     out.meshes.resize(n_mesh);
@@ -510,17 +554,18 @@ int build_flat_scene(const RtSceneDesc* d, FlatScene& out, std::string& err) {
     for (uint64_t m = 0; m < n_mesh; m++) {
         const RtMesh& mesh = d->meshes[m];
         const Tree& t = blas[m];
-        const uint32_t node_base = (uint32_t)out.nodes.size();
         const uint32_t tri_base = (uint32_t)out.tri_hot.size();
-        Tree walk;
-        bool own = false;
-        if (walk_trees) { walk = build_walk_tree(t); own = emitted_depth(walk) <= std::max(kMaxWalkDepth, emitted_depth(t)); }
-        Emitter be{out.nodes, node_base, own ? walk : t};
-        const uint32_t root = be.emit(0, 0);
+        {
+            Tree walk;
+            bool own = false;
+            if (walk_trees) { walk = build_walk_tree(t); own = emitted_depth(walk) <= std::max(kMaxWalkDepth, emitted_depth(t)); }
+            emitters.emplace_back(new Emitter(own ? walk : t));     // (the emitter keeps no reference to `walk` after its constructor)
+        }
+        const Emitter& be = *emitters.back();
         if (be.depth > blas_walk_depth) blas_walk_depth = be.depth;
         blas_depth = std::max(blas_depth, emitted_depth(t));
         DevMesh& dm = out.meshes[m];
-        dm.w[0].u[0] = node_base; dm.w[0].u[1] = tri_base; dm.w[0].u[2] = (uint32_t)mesh.tri_count; dm.w[0].u[3] = root;
+        dm.w[0].u[0] = 0; dm.w[0].u[1] = tri_base; dm.w[0].u[2] = (uint32_t)mesh.tri_count; dm.w[0].u[3] = 0;      // root ref: below
         const Box& rb = t.nodes[0].box;
         dm.w[1].f[0] = rb.lo.x; dm.w[1].f[1] = rb.lo.y; dm.w[1].f[2] = rb.lo.z; dm.w[1].f[3] = rb.hi.x;
         dm.w[2].f[0] = rb.hi.y; dm.w[2].f[1] = rb.hi.z; dm.w[2].f[2] = 0.0f; dm.w[2].f[3] = 0.0f;
@@ -547,6 +592,44 @@ int build_flat_scene(const RtSceneDesc* d, FlatScene& out, std::string& err) {
             out.tri_rank.push_back(rank[p]);
         }
         tri_total += mesh.tri_count;
+    }
+    // traversal stack: one deferred sibling per inner level of the TLAS, one
+    // TLAS-leaf continuation, one per inner level of the deepest BLAS, + margin
+    v.stack_entries = tlas_walk_depth + 1 + blas_walk_depth + 2;
+
+    // ---- node records: the top levels of every tree first (the LDS node cache), then the rest --------
+    // LDS of a render block = its lanes' traversal stacks + the cache; four blocks share a CU's 160 KB.
+    {
+        const size_t stack_bytes = ((size_t)v.stack_entries + 3) * RT_BLOCK * sizeof(uint32_t);
+        const size_t block_budget = 160 * 1024 / 4;
+        static const int cap = []() { const char* e = getenv("RT_LDS_NODES"); return e ? atoi(e) : 1 << 20; }();     // 0 turns the cache off
+        size_t budget = stack_bytes < block_budget ? (block_budget - stack_bytes) / RT_NODE_CACHE_STRIDE : 0;
+        if (budget > (size_t)cap) budget = (size_t)cap;
+        // equal shares for the trees, what a small tree leaves goes to the others (in order)
+        std::vector<uint32_t> hot(emitters.size(), 0);
+        size_t open = 0; for (auto& e : emitters) if (!e->en.empty()) open++;
+        size_t left = budget;
+        for (int pass = 0; pass < 4 && left && open; pass++) {
+            const size_t share = std::max<size_t>(left / open, 1);
+            open = 0;
+            for (size_t k = 0; k < emitters.size() && left; k++) {
+                const size_t room = emitters[k]->en.size() - hot[k];
+                const size_t take = std::min({room, share, left});
+                hot[k] += (uint32_t)take; left -= take;
+                if (emitters[k]->en.size() > hot[k]) open++;
+            }
+        }
+        size_t n_hot = 0, n_all = 0;
+        for (size_t k = 0; k < emitters.size(); k++) { n_hot += hot[k]; n_all += emitters[k]->en.size(); }
+        out.nodes.assign(n_all ? n_all : 1, DevNode{});
+        uint32_t hot_at = 0, cold_at = (uint32_t)n_hot;
+        for (size_t k = 0; k < emitters.size(); k++) {
+            const uint32_t ref = emitters[k]->write(out.nodes, hot_at, hot[k], cold_at);
+            if (k == 0) v.tlas_root_ref = ref; else out.meshes[k - 1].w[0].u[3] = ref;
+            hot_at += hot[k]; cold_at += (uint32_t)emitters[k]->en.size() - hot[k];
+            emitters[k].reset();
+        }
+        v.lds_nodes = (uint32_t)n_hot;
     }
     out.info.blas_node_count = out.nodes.size() - out.info.tlas_node_count;
     out.info.blas_depth = blas_depth;
@@ -647,9 +730,6 @@ int build_flat_scene(const RtSceneDesc* d, FlatScene& out, std::string& err) {
     if (out.meshes.empty()) out.meshes.emplace_back();
     if (out.tri_hot.empty()) { out.tri_hot.emplace_back(); out.tri_cold.emplace_back(); out.tri_rank.push_back(0); }
 
-    // traversal stack: one deferred sibling per inner level of the TLAS, one
-    // TLAS-leaf continuation, one per inner level of the deepest BLAS, + margin
-    v.stack_entries = tlas_walk_depth + 1 + blas_walk_depth + 2;
     lap("materials, textures, lights");
     return RT_OK;
 }
