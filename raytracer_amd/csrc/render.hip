@@ -614,7 +614,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
     // scene_build.cpp) are read from LDS instead of through the vector memory path: the texture
     // addresser is 70-80 % busy with the gathers of this kernel (18 cycles per wave instruction), and
     // every ray walks the top levels (weekend +6 %).
-    uint32_t* const node_cache = lds_stack + (stack_cap + 3u) * RT_BLOCK;
+    uint32_t* const node_cache = lds_stack + (stack_cap + (S.mesh_entities ? 3u : 0u)) * RT_BLOCK;      // (three rows park 1/d while a lane is inside an instance)
     for (uint32_t i = threadIdx.x; i < S.lds_nodes * 4u; i += RT_BLOCK) {
         const float4 v = *reinterpret_cast<const float4*>(&S.nodes[i >> 2].w[i & 3u]);
         *reinterpret_cast<float4*>(node_cache + (i >> 2) * (RT_NODE_CACHE_STRIDE / 4u) + (i & 3u) * 4u) = v;
@@ -1482,7 +1482,7 @@ RtScene* rt_scene_create(const RtSceneDesc* desc, int device) {
         upload(s, flat.texels, &s->view.texels) || upload(s, flat.lights, &s->view.lights))
         return fail();
     // launch shape: a resident grid (persistent lanes stride over the work items)
-    s->lds_bytes = ((size_t)s->view.stack_entries + 3) * RT_BLOCK * sizeof(uint32_t);      // + 3 rows: parked world-space 1/d
+    s->lds_bytes = ((size_t)s->view.stack_entries + (s->view.mesh_entities ? 3 : 0)) * RT_BLOCK * sizeof(uint32_t);      // + 3 rows: parked world-space 1/d
     s->stack_lds_bytes = s->lds_bytes;
     s->lds_bytes += (size_t)s->view.lds_nodes * RT_NODE_CACHE_STRIDE;      // the node cache (sized by scene_build.cpp to fit four blocks per CU)
     if (s->stack_lds_bytes > 64 * 1024) { set_error(RT_E_DEPTH, "BVH too deep for the LDS traversal stack (more than 64 levels)"); return fail(); }
