@@ -1323,6 +1323,9 @@ int validate_call(const RtScene* scene, const RtSettings* st, const RtRenderChun
     if (st->max_reflections > RT_MAX_REFLECTIONS) return set_error(RT_E_LIMIT, "RenderSettings: max_reflections is limited to 31 (recursion-tree node id is 32 bit)");
     if (ch->width == 0 || ch->height == 0) return set_error(RT_E_INVALID, "RenderChunk: empty chunk");
     if ((uint64_t)ch->left + ch->width > st->width || (uint64_t)ch->top + ch->height > st->height) return set_error(RT_E_INVALID, "RenderChunk: outside the image");
+    // work items of a launch are counted in 32 bits, scratch is sized per chunk: 2^28 pixels (16384 x 16384) per call
+    if ((((uint64_t)ch->width + 7) / 8) * (((uint64_t)ch->height + 7) / 8) * 64 > (1ull << 28))
+        return set_error(RT_E_LIMIT, "RenderChunk: more than 2^28 pixels in one call; render the image in several chunks (create_render_chunks)");
     return RT_OK;
 }
 

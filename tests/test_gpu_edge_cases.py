@@ -101,6 +101,12 @@ def test_argument_errors():
             scene.render_chunk(st, ch)
     with pytest.raises(RtError, match="out of range"):
         Scene(basic_scene(), 99)
+    # more than 2^28 pixels in one call (the work items of a launch are counted in 32 bits): refused before anything is touched
+    import torch
+    tiny = torch.zeros(16, dtype=torch.float32, device="cuda:0")
+    with pytest.raises(RtError, match="2\\^28 pixels"):
+        scene.render_chunk_device(RenderSettings(40000, 40000, 3, 1), RenderChunk(0, 0, 40000, 40000), 1, tiny.data_ptr(), None, 40000, 0, 0,
+                                  None, torch.cuda.current_stream().cuda_stream)
     again, _, _ = scene.render_chunk(ok, RenderChunk(0, 0, 8, 8))       # the scene is still usable after errors
     assert again.shape == (8, 8, 3)
 
