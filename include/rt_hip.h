@@ -242,7 +242,9 @@ void     rt_scene_destroy(RtScene* scene);
  *              the key of a counter-based RNG addressed (seed,x,y,sample,node):
  *              the image does not depend on chunking or GPU count.
  *   counters : nullable; rays are ADDED to it.
- * Host pointers; the call blocks until the pixels are in the buffers. */
+ * Host pointers; the call blocks until the pixels are in the buffers.
+ * Limits (RT_E_LIMIT): image sides <= 65535, max_reflections <= 31, at most 2^28
+ * pixels per chunk call (render larger images chunk by chunk). */
 int rt_render_chunk(RtScene* scene, const RtSettings* settings,
                     const RtRenderChunk* chunk, uint64_t seed,
                     float* rgb_out, uint8_t* rgba_out, RtRayCounters* counters);
