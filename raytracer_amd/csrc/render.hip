@@ -593,6 +593,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
     uint32_t pxy = 0, s = RT_NONE;           // pixel (x | y << 16) and sample index of the lane's current round (RT_NONE: no sample)
     // the wave's current block (wave-uniform): tile, unit, rounds started
     uint32_t blk_tile = 0, blk_unit = 0, round_next = 0;
+    uint32_t blk_xy0 = 0, blk_py0 = 0;          // the tile's first pixel: chunk-local x | y << 16, and its image row
     F3 sample_col = f3(0, 0, 0);
     Pending pend[RT_PENDING_MAX]; uint32_t npend = 0;
     F3 ro = f3(0, 0, 0), rd = f3(0, 0, 1), rw = f3(0, 0, 0); uint32_t rlimit = 0, rnode = 0;   // current path ray
@@ -650,6 +651,12 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                     if (blk < heavy_blocks) { tile_rank = blk / P.unit_count; unit_local = blk % P.unit_count; }
                     else { const uint32_t b = blk - heavy_blocks, rest = n_tiles - heavy; unit_local = b / rest; tile_rank = heavy + b % rest; }
                     blk_tile = P.tile_order ? P.tile_order[tile_rank] : tile_rank;
+                    {
+                        const uint32_t x0 = (blk_tile % P.tiles_x) * 8u, y0 = (blk_tile / P.tiles_x) * 8u;
+                        blk_xy0 = x0 | (y0 << 16);
+                        // (strips are whole rows of tiles, so the 8 rows of a tile are consecutive image rows)
+                        blk_py0 = P.strip_h ? P.strip_first_row + (y0 / P.strip_h) * P.strip_period_rows + (y0 % P.strip_h) : P.top + y0;
+                    }
                     blk_unit = unit_local;
                     round_next = 0u; s = RT_NONE;         // the block's rays are dealt to the lanes round by round, below
                     state = NEED_SAMPLE;
@@ -800,13 +807,14 @@ render_kernel(const DevSceneView S, const RenderParams P) {
         // of 64 rays and every lane waits for the round to end, so the rays traced side by side are of one
         // kind (camera rays with camera rays, shadow rays with shadow rays), which keeps the lanes in step
         // through the tree (measured against free-running lanes: weekend +5 %, mesh_demo +41 %).
-        // A round is ALL samples of the unit for 64 / unit_len pixels (whole-segment units: the 8 samples of
-        // one row of the tile, lane = sample * 8 + column; one-sample units: all 64 pixels).  Samples of one
-        // pixel meet the same materials, so the lanes of a round have paths of similar length, and a wave
-        // waits for the longest path of 8 pixels instead of 64 (measured against one sample of 64 pixels
-        // per round: weekend +2 %, Dreadnaught +13 %, instanced meshes +24 %).
-        // The clamped samples of a pixel are added in sample order, ((0 + c0) + c1) + ..., by handing them to
-        // the pixel's first lane one after the other (cast_rays_into_scene's col = col + sample, :656).
+        // A round holds samples of as few pixels as possible: up to 8 units of a tile share their rounds, so
+        // with 64 or more samples per pixel a round is 64 samples of ONE pixel (lane = unit * 8 + sample),
+        // with fewer units 2, 4 or 8 pixels of a compact group; one-sample units (fine split): one sample of
+        // all 64 pixels.  Samples of one pixel meet the same materials, so the lanes of a round have paths
+        // of similar length, and a wave waits for the longest path of one pixel instead of 64 (measured
+        // against one sample of 64 pixels per round: Dreadnaught +32 %, instanced meshes +76 %).
+        // The clamped samples of a unit are added in sample order, ((0 + c0) + c1) + ..., by handing them to
+        // the unit's first lane one after the other (cast_rays_into_scene's col = col + sample, :656).
         if (__ballot(tracing || state != NEED_SAMPLE) == 0ull) {        // wave-uniform: every lane has finished its sample
             // lane = (unit of the group, sample of the unit, pixel of the round); all sizes are powers of two
             const uint32_t l_shift = P.unit_len == 1u ? 0u : RT_SEGMENT_SHIFT, k_shift = P.round_units_shift;
@@ -814,7 +822,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
             const uint32_t q = lane & ((1u << g_shift) - 1u), j = lane >> g_shift;
             const uint32_t u_in = j >> l_shift, jj = j & (P.unit_len - 1u);
             const uint32_t sub = blk_unit & ((1u << k_shift) - 1u), unit_local = ((blk_unit >> k_shift) << k_shift) + u_in;
-            const uint32_t x0 = (blk_tile % P.tiles_x) * 8u, y0 = (blk_tile / P.tiles_x) * 8u;
+            const uint32_t x0 = blk_xy0 & 0xffffu, y0 = blk_xy0 >> 16;
             const uint32_t s_mine = (P.unit_first + unit_local) * P.unit_len + jj;
             const bool s_ok = s_mine >= P.sample_first && s_mine < P.sample_first + P.sample_count;
             // pixel of this lane in round g: Z-order inside the tile, so that the pixels of a round and of a
@@ -842,12 +850,10 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                 if (round_next == P.unit_len) { state = NEED_BLOCK; break; }      // wait for the wave's next block
                 uint32_t x, y; round_pixel(round_next, x, y);
                 round_next++;
-                x += x0; y += y0;
-                s = (x < P.cw && y < P.ch && s_ok) ? s_mine : RT_NONE;      // lanes off the chunk's edge sit the round out
+                s = (x0 + x < P.cw && y0 + y < P.ch && s_ok) ? s_mine : RT_NONE;      // lanes off the chunk's edge sit the round out
                 if (s != RT_NONE) {
                     PH(PH_STAGE_C);
-                    const uint32_t px = P.left + x;
-                    const uint32_t py = P.strip_h ? P.strip_first_row + (y / P.strip_h) * P.strip_period_rows + (y % P.strip_h) : P.top + y;
+                    const uint32_t px = P.left + x0 + x, py = blk_py0 + y;
                     pxy = px | (py << 16);
                     float pu, pv; pixel_uv(P, px, py, pu, pv);
                     float lx = 0.0f, ly = 0.0f;
