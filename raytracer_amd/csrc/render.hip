@@ -525,7 +525,6 @@ struct RenderParams {
     uint32_t tiles_x, pix_slots;                    // 8x8 tiling of the chunk; pix_slots = tiles*64
     float* partial;                                 // [unit_count][tile][64][3] sums of the clamped samples of each unit (8x8 tiles of the chunk)
     unsigned long long* counters;                   // RtRayCounters on the device (nullable)
-    uint32_t refill_lanes;                          // idle lanes that end a traversal burst
     uint32_t* block_counter;                        // RT_QUEUES counters, 64 B apart (zeroed per launch): next unclaimed block of each queue
     const uint32_t* tile_order;                     // k-th tile to hand out, expensive ones first; [-1] = how many are expensive; null = row-major
 #ifdef RT_PHASE_STATS
@@ -548,7 +547,9 @@ __device__ __forceinline__ void gen_camera_ray(const DevSceneView& S, float u, f
 }
 
 // How many lanes of a wave must be waiting for a new ray before the wave leaves
-// the traversal burst to shade / refill them (persistent-thread ray refill).
+// the traversal burst to shade / refill them (persistent-thread ray refill).  Every
+// threshold below 64 (= synchronous: the burst ends with its last ray) measured slower
+// (DESIGN.md 4.3), so it is a build option (-DRT_REFILL_LANES=n), not a run-time one.
 #ifndef RT_REFILL_LANES
 #define RT_REFILL_LANES 64
 #endif
@@ -1046,8 +1047,12 @@ render_kernel(const DevSceneView S, const RenderParams P) {
             }
             // leave the burst when enough lanes can take a new ray, or nobody is tracing
             const unsigned long long busy = __ballot(tracing);
+#if RT_REFILL_LANES < 64
             const unsigned long long refill = __ballot(!tracing && state != FINISHED && state != NEED_BLOCK);
-            if (busy == 0ull || (uint32_t)__popcll(refill) >= P.refill_lanes) break;
+            if (busy == 0ull || (uint32_t)__popcll(refill) >= (uint32_t)RT_REFILL_LANES) break;
+#else
+            if (busy == 0ull) break;          // synchronous: the burst ends when every ray of the wave has ended
+#endif
         }
     }
 
@@ -1379,10 +1384,6 @@ int enqueue_accumulate(RtScene* scene, Workspace& ws, const RtSettings* st, cons
     P.partial = (float*)ws.partial.p;
     P.counters = counters_dev;
     P.strip_h = il.strip_h; P.strip_period_rows = il.period_rows; P.strip_first_row = il.first_row;
-    {
-        static const uint32_t refill = []() { const char* e = getenv("RT_REFILL_LANES"); int v = e ? atoi(e) : RT_REFILL_LANES; return (uint32_t)(v < 1 ? 1 : (v > 64 ? 64 : v)); }();
-        P.refill_lanes = refill;
-    }
     // expensive tiles first (whole-segment launches over enough tiles to have a tail worth hiding)
     const uint32_t n_tiles = pix_slots / 64;
     static const bool order_tiles = []() { const char* e = getenv("RT_TILE_ORDER"); return !e || atoi(e) != 0; }();
