@@ -546,6 +546,20 @@ __device__ __forceinline__ void gen_camera_ray(const DevSceneView& S, float u, f
     d = ld3(S.cam_llc) + (ld3(S.cam_horizontal) * u) + (ld3(S.cam_vertical) * v) - ld3(S.cam_origin) - offset;
 }
 
+// Sum of the 8 values held by this lane and the 7 lanes STRIDE, 2*STRIDE, ... above it (same row of
+// 16 lanes), added one after the other: ((0 + c0) + c1) + ... + c7.  DPP row shifts feed the adds
+// directly (no LDS permute); lanes without 7 lanes above them in their row compute a value nobody reads.
+template <int CTRL> __device__ __forceinline__ float dpp_read(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+template <int STRIDE> __device__ __forceinline__ float seq_sum8(float c) {
+    float s = 0.0f + c;
+    s = s + dpp_read<0x100 + 1 * STRIDE>(c); s = s + dpp_read<0x100 + 2 * STRIDE>(c); s = s + dpp_read<0x100 + 3 * STRIDE>(c);
+    s = s + dpp_read<0x100 + 4 * STRIDE>(c); s = s + dpp_read<0x100 + 5 * STRIDE>(c); s = s + dpp_read<0x100 + 6 * STRIDE>(c);
+    s = s + dpp_read<0x100 + 7 * STRIDE>(c);
+    return s;
+}
+
 // How many lanes of a wave must be waiting for a new ray before the wave leaves
 // the traversal burst to shade / refill them (persistent-thread ray refill).  Every
 // threshold below 64 (= synchronous: the burst ends with its last ray) measured slower
@@ -838,7 +852,10 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                     // close the round: segment sums of its pixels, ((0 + c0) + c1) + ... in sample order
                     const F3 c = s != RT_NONE ? sample_col : f3(0.0f, 0.0f, 0.0f);     // (x + 0 == x: the sum is never -0)
                     F3 sum = f3(0.0f, 0.0f, 0.0f);
-                    for (uint32_t k = 0; k < P.unit_len; k++) {
+                    static_assert(RT_SAMPLE_SEGMENT == 8u, "seq_sum8 adds the 8 samples of a segment");
+                    if (l_shift != 0u && g_shift == 0u) sum = f3(seq_sum8<1>(c.x), seq_sum8<1>(c.y), seq_sum8<1>(c.z));          // the unit's samples: 8 consecutive lanes
+                    else if (l_shift != 0u && g_shift == 1u) sum = f3(seq_sum8<2>(c.x), seq_sum8<2>(c.y), seq_sum8<2>(c.z));     // every second lane
+                    else for (uint32_t k = 0; k < P.unit_len; k++) {
                         const int src = (int)(((((u_in << l_shift) + k)) << g_shift) | q);
                         sum = sum + f3(__shfl(c.x, src, 64), __shfl(c.y, src, 64), __shfl(c.z, src, 64));
                     }
