@@ -41,6 +41,9 @@ struct alignas(64) DevNode { Word4 w[4]; };
 #ifndef RT_BLOCK
 #define RT_BLOCK 256
 #endif
+#ifndef RT_WAVES_PER_SIMD
+#define RT_WAVES_PER_SIMD 4     /* resident waves per SIMD the render kernel is built for: 512 / 4 -> 128 VGPRs; 3 and 5 measured slower */
+#endif
 #define RT_NODE_CACHE_STRIDE 80u
 
 // ---- Entity (implementation.rs:224-230), stored in TLAS leaf order ----------

@@ -53,9 +53,6 @@
 #ifndef RT_QUEUES
 #define RT_QUEUES 16u            /* block counters per launch, one cache line each */
 #endif
-#ifndef RT_WAVES_PER_SIMD
-#define RT_WAVES_PER_SIMD 4     /* register budget of the render kernel: 512 / 4 -> 128 VGPRs */
-#endif
 #define RT_MAX_REFLECTIONS 31u
 
 

@@ -601,7 +601,7 @@ int build_flat_scene(const RtSceneDesc* d, FlatScene& out, std::string& err) {
     // LDS of a render block = its lanes' traversal stacks + the cache; four blocks share a CU's 160 KB.
     {
         const size_t stack_bytes = ((size_t)v.stack_entries + (d->mesh_object_count ? 3 : 0)) * RT_BLOCK * sizeof(uint32_t);      // as rt_scene_create sizes it
-        const size_t block_budget = 160 * 1024 / 4;
+        const size_t block_budget = (size_t)160 * 1024 * RT_BLOCK / (256 * RT_WAVES_PER_SIMD);      // RT_WAVES_PER_SIMD x 256 lanes share a CU's LDS
         static const int cap = []() { const char* e = getenv("RT_LDS_NODES"); return e ? atoi(e) : 1 << 20; }();     // 0 turns the cache off
         size_t budget = stack_bytes < block_budget ? (block_budget - stack_bytes) / RT_NODE_CACHE_STRIDE : 0;
         if (budget > (size_t)cap) budget = (size_t)cap;
