@@ -576,7 +576,9 @@ enum { PH_NODE = 0, PH_TRI, PH_ENTITY, PH_SHADE, PH_SHADE_PATH_HIT, PH_SHADE_SHA
 
 // LOOSE: the scene has entity boxes that do not bound their hits (device_scene.h, loose_boxes):
 // TLAS boxes are then tested against the ray's whole interval, as the reference does for every box.
-template <bool LOOSE>
+// MESH: the scene has mesh instances (MESH); scenes of spheres and planes only run an instantiation
+// without the BLAS code and its per-lane state (weekend +4 %).
+template <bool LOOSE, bool MESH>
 __global__ void __launch_bounds__(RT_BLOCK, RT_WAVES_PER_SIMD)
 render_kernel(const DevSceneView S, const RenderParams P) {
     extern __shared__ uint32_t lds_stack[];
@@ -627,7 +629,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
     // scene_build.cpp) are read from LDS instead of through the vector memory path: the texture
     // addresser is 70-80 % busy with the gathers of this kernel (18 cycles per wave instruction), and
     // every ray walks the top levels (weekend +6 %).
-    uint32_t* const node_cache = lds_stack + (stack_cap + (S.mesh_entities ? 3u : 0u)) * RT_BLOCK;      // (three rows park 1/d while a lane is inside an instance)
+    uint32_t* const node_cache = lds_stack + (stack_cap + (MESH ? 3u : 0u)) * RT_BLOCK;      // (three rows park 1/d while a lane is inside an instance)
     for (uint32_t i = threadIdx.x; i < S.lds_nodes * 4u; i += RT_BLOCK) {
         const float4 v = *reinterpret_cast<const float4*>(&S.nodes[i >> 2].w[i & 3u]);
         *reinterpret_cast<float4*>(node_cache + (i >> 2) * (RT_NODE_CACHE_STRIDE / 4u) + (i & 3u) * 4u) = v;
@@ -895,7 +897,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                 o = shadow ? hp : ro;
                 d = shadow ? -ldir : rd;
                 inv = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-                if (S.mesh_entities) {      // read back when the walk leaves an instance (three divisions saved per exit)
+                if (MESH) {      // read back when the walk leaves an instance (three divisions saved per exit)
                     stack[stack_cap * RT_BLOCK] = __float_as_uint(inv.x); stack[(stack_cap + 1u) * RT_BLOCK] = __float_as_uint(inv.y);
                     stack[(stack_cap + 2u) * RT_BLOCK] = __float_as_uint(inv.z);
                 }
@@ -913,7 +915,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
         // ================= traversal burst ===================================================
         // next deferred subtree; leaving a BLAS restores the world-space ray
         auto pop = [&]() -> uint32_t {
-            if (sp == inst_sp) {
+            if (MESH && sp == inst_sp) {
                 PH(PH_POP_INST);
                 inst_sp = RT_NONE;
                 const bool shadow = state == SHADOW;
@@ -956,7 +958,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                 if (cur != RT_NONE) {
                     const uint32_t first = cur & RT_REF_FIRST_MASK;
                     const uint32_t count = ((cur >> RT_REF_COUNT_SHIFT) & 7u) + 1u;
-                    if (inst_sp != RT_NONE) {
+                    if (MESH && inst_sp != RT_NONE) {
                         PH(PH_LEAF_TRI);
                         // try_hit_tri, mesh.rs:18-76 (normal precomputed with the same ops)
                         for (uint32_t k = 0; k < count; k++) {
@@ -1028,7 +1030,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                                     hit = !(t < t_min || t > t_max);
                                     if (hit && p1.u[3]) { const F3 p = eo + (ed * t); hit = !(length(p) > p0.f[3]); }
                                 }
-                            } else {
+                            } else if (MESH) {
                                 // MeshObject::hit -> BLAS (mesh.rs:161-176): enter the instance
                                 const Word4* mw = S.meshes[e1.u[1]].w;
                                 const Word4 m0 = ldw(mw), m1 = ldw(mw + 1), m2 = ldw(mw + 2);
@@ -1441,8 +1443,14 @@ int enqueue_accumulate(RtScene* scene, Workspace& ws, const RtSettings* st, cons
         HIP_TRY(hipMemsetAsync(phase_dev, 0, PH_COUNT * 16, stream));
         P.phase_stats = phase_dev;
 #endif
-        if (scene->view.loose_boxes) hipLaunchKernelGGL(render_kernel<true>, dim3((uint32_t)blocks), dim3(RT_BLOCK), scene->lds_bytes, stream, scene->view, P);
-        else hipLaunchKernelGGL(render_kernel<false>, dim3((uint32_t)blocks), dim3(RT_BLOCK), scene->lds_bytes, stream, scene->view, P);
+        {
+            const dim3 grid((uint32_t)blocks), block(RT_BLOCK);
+            const bool loose = scene->view.loose_boxes != 0, mesh = scene->view.mesh_entities != 0;
+            if (loose && mesh) hipLaunchKernelGGL((render_kernel<true, true>), grid, block, scene->lds_bytes, stream, scene->view, P);
+            else if (loose) hipLaunchKernelGGL((render_kernel<true, false>), grid, block, scene->lds_bytes, stream, scene->view, P);
+            else if (mesh) hipLaunchKernelGGL((render_kernel<false, true>), grid, block, scene->lds_bytes, stream, scene->view, P);
+            else hipLaunchKernelGGL((render_kernel<false, false>), grid, block, scene->lds_bytes, stream, scene->view, P);
+        }
         HIP_TRY(hipGetLastError());
 #ifdef RT_PHASE_STATS
         {
@@ -1513,7 +1521,7 @@ RtScene* rt_scene_create(const RtSceneDesc* desc, int device) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { set_error(RT_E_HIP, "hipGetDeviceProperties failed"); return fail(); }
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_kernel<false>, RT_BLOCK, s->lds_bytes) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_kernel<false, true>, RT_BLOCK, s->lds_bytes) != hipSuccess || per_cu < 1) per_cu = 1;
     s->grid_blocks = prop.multiProcessorCount * per_cu;
     if (s->shared.init(false)) return fail();
     return s;
