@@ -578,7 +578,9 @@ enum { PH_NODE = 0, PH_TRI, PH_ENTITY, PH_SHADE, PH_SHADE_PATH_HIT, PH_SHADE_SHA
 // TLAS boxes are then tested against the ray's whole interval, as the reference does for every box.
 // MESH: the scene has mesh instances (MESH); scenes of spheres and planes only run an instantiation
 // without the BLAS code and its per-lane state (weekend +4 %).
-template <bool LOOSE, bool MESH>
+// GLASS: some material is a dielectric (!S.shadow_any_hit); without one there is no refraction, so no
+// deferred child rays (the per-lane array in scratch), and the first occluder decides a shadow ray.
+template <bool LOOSE, bool MESH, bool GLASS>
 __global__ void __launch_bounds__(RT_BLOCK, RT_WAVES_PER_SIMD)
 render_kernel(const DevSceneView S, const RenderParams P) {
     extern __shared__ uint32_t lds_stack[];
@@ -696,7 +698,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                     const uint32_t mat_id = ldw(S.entities[best.ent].w + 1).u[3];
                     const Word4* mw = S.materials[mat_id].w;
                     const Word4 m0 = ldw(mw);
-                    if (m0.u[0] == RT_MAT_DIELECTRIC) {
+                    if (GLASS && m0.u[0] == RT_MAT_DIELECTRIC) {
                         const F3 td = -ldir;
                         HitRec hr; resolve_hit(S, hp, td, best, hr);
                         float nint; F3 outn;
@@ -736,7 +738,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                             scattered = reflected + (unit(random_normal_reflection_angle(hr.normal, r0, r1)) * m0.f[2]);
                         }
                         if (dot(scattered, hr.normal) > 0.0f) { has_refl = true; refl_d = scattered; refl_i = m0.f[1]; }
-                    } else {                                                                  // materials.rs:167-204
+                    } else if (GLASS) {                                                       // materials.rs:167-204
                         float ni_over_nt; F3 outward_normal;
                         const float kr = dielectric_kr(rd, hr.normal, ldw(mw + 1).f[0], ni_over_nt, outward_normal);
                         if (!(kr >= 1.0f)) {
@@ -1058,7 +1060,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                     }
                 }
                 // a shadow ray of a scene without dielectrics is decided by ANY occluder
-                if (S.shadow_any_hit && state == SHADOW && best.ent != RT_NONE) cur = RT_NONE;
+                if (!GLASS && state == SHADOW && best.ent != RT_NONE) cur = RT_NONE;
                 if (cur == RT_NONE) tracing = false;      // closest hit (or miss) is in `best`
             }
             // leave the burst when enough lanes can take a new ray, or nobody is tracing
@@ -1444,12 +1446,13 @@ int enqueue_accumulate(RtScene* scene, Workspace& ws, const RtSettings* st, cons
         P.phase_stats = phase_dev;
 #endif
         {
-            const dim3 grid((uint32_t)blocks), block(RT_BLOCK);
-            const bool loose = scene->view.loose_boxes != 0, mesh = scene->view.mesh_entities != 0;
-            if (loose && mesh) hipLaunchKernelGGL((render_kernel<true, true>), grid, block, scene->lds_bytes, stream, scene->view, P);
-            else if (loose) hipLaunchKernelGGL((render_kernel<true, false>), grid, block, scene->lds_bytes, stream, scene->view, P);
-            else if (mesh) hipLaunchKernelGGL((render_kernel<false, true>), grid, block, scene->lds_bytes, stream, scene->view, P);
-            else hipLaunchKernelGGL((render_kernel<false, false>), grid, block, scene->lds_bytes, stream, scene->view, P);
+            // one instantiation per combination of scene traits (code and per-lane state a scene does not need are compiled out)
+            using Kernel = void (*)(const DevSceneView, const RenderParams);
+            static const Kernel kernels[8] = {render_kernel<false, false, false>, render_kernel<false, false, true>, render_kernel<false, true, false>,
+                                              render_kernel<false, true, true>,   render_kernel<true, false, false>, render_kernel<true, false, true>,
+                                              render_kernel<true, true, false>,   render_kernel<true, true, true>};
+            const int which = (scene->view.loose_boxes ? 4 : 0) | (scene->view.mesh_entities ? 2 : 0) | (scene->view.shadow_any_hit ? 0 : 1);
+            hipLaunchKernelGGL(kernels[which], dim3((uint32_t)blocks), dim3(RT_BLOCK), scene->lds_bytes, stream, scene->view, P);
         }
         HIP_TRY(hipGetLastError());
 #ifdef RT_PHASE_STATS
@@ -1521,7 +1524,7 @@ RtScene* rt_scene_create(const RtSceneDesc* desc, int device) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { set_error(RT_E_HIP, "hipGetDeviceProperties failed"); return fail(); }
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_kernel<false, true>, RT_BLOCK, s->lds_bytes) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_kernel<false, true, true>, RT_BLOCK, s->lds_bytes) != hipSuccess || per_cu < 1) per_cu = 1;
     s->grid_blocks = prop.multiProcessorCount * per_cu;
     if (s->shared.init(false)) return fail();
     return s;
