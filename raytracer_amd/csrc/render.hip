@@ -178,10 +178,13 @@ __device__ __forceinline__ void slab2(const Word4& a, const Word4& b, const Word
 }
 
 // Entity::hit's world -> entity ray transform, implementation.rs:288-294
+// GENERAL = false: the scene has no plane and every entity has exactly one translation and no rotation
+// (DevSceneView::general_entities == 0), so only the inline translation is ever needed.
+template <bool GENERAL = true>
 __device__ __forceinline__ void ray_to_entity(const DevSceneView& S, const Word4& e0, const Word4& e1, F3& o, F3& d) {
     const uint32_t packed = e1.u[0];
     const uint32_t n_trans = (packed >> 8) & 0xff, n_rot = (packed >> 16) & 0xff;
-    if (n_trans == 1 && n_rot == 0) { o = o - w3(e0); return; }     // translation kept inline
+    if (!GENERAL || (n_trans == 1 && n_rot == 0)) { o = o - w3(e0); return; }     // translation kept inline
     const Word4* x = S.xforms + e1.u[2];
     for (uint32_t k = 0; k < n_trans; k++) o = o - w3(ldw(x + k));
     x += n_trans;
@@ -341,24 +344,25 @@ __device__ __forceinline__ void trace(const DevSceneView& S, const F3 wo, const 
 // ===========================================================================
 struct HitRec { F3 p, normal; float u, v; uint32_t mat_id, tex_id; int32_t tex_key; int32_t entity_index, tri_index; };
 
+template <bool GENERAL = true, bool MESH = true>
 __device__ __forceinline__ void resolve_hit(const DevSceneView& S, F3 o, F3 d, const Hit& h, HitRec& r) {
     const Word4* ew = S.entities[h.ent].w;
     const Word4 e0 = ldw(ew), e1 = ldw(ew + 1), e2 = ldw(ew + 2);
     const uint32_t kind = e1.u[0] & 0xff;
-    ray_to_entity(S, e0, e1, o, d);
+    ray_to_entity<GENERAL>(S, e0, e1, o, d);
     r.mat_id = e1.u[3]; r.tex_id = e2.u[0]; r.entity_index = (int32_t)e2.u[1]; r.tex_key = -1; r.tri_index = -1;
     const float t = h.t;
     F3 p = o + (d * t), normal;
     r.u = 0.0f; r.v = 0.0f;
-    if (kind == RT_HITABLE_SPHERE) {
+    if ((!GENERAL && !MESH) || kind == RT_HITABLE_SPHERE) {
         normal = unit(p / e0.f[3]);                                              // sphere.rs:40-41
-    } else if (kind == RT_HITABLE_PLANE) {
+    } else if (GENERAL && kind == RT_HITABLE_PLANE) {
         const Word4* pw = S.planes[e1.u[1]].w;
         const Word4 p0 = ldw(pw), p1 = ldw(pw + 1), p2 = ldw(pw + 2);
         const F3 pn = w3(p0);
         normal = dot(d, pn) > 0.0f ? -pn : pn;                                   // plane.rs:73
         r.u = dot(w3(p1), p); r.v = dot(w3(p2), p);                              // plane.rs:75-79
-    } else {
+    } else if (MESH) {
         const Word4* tw = S.tri_hot[h.tri].w;
         const Word4 wa = ldw(tw), wb = ldw(tw + 1), wc = ldw(tw + 2);
         const Word4* cw = S.tri_cold[h.tri].w;
@@ -377,7 +381,7 @@ __device__ __forceinline__ void resolve_hit(const DevSceneView& S, F3 o, F3 d, c
     }
     // implementation.rs:300-306: rotations reversed (+theta), then translations reversed
     const uint32_t n_trans = (e1.u[0] >> 8) & 0xff, n_rot = (e1.u[0] >> 16) & 0xff;
-    if (n_trans == 1 && n_rot == 0) p = p + w3(e0);
+    if (!GENERAL || (n_trans == 1 && n_rot == 0)) p = p + w3(e0);
     else {
         const Word4* x = S.xforms + e1.u[2];
         for (uint32_t k = n_rot; k-- > 0;) {
@@ -580,7 +584,9 @@ enum { PH_NODE = 0, PH_TRI, PH_ENTITY, PH_SHADE, PH_SHADE_PATH_HIT, PH_SHADE_SHA
 // without the BLAS code and its per-lane state (weekend +4 %).
 // GLASS: some material is a dielectric (!S.shadow_any_hit); without one there is no refraction, so no
 // deferred child rays (the per-lane array in scratch), and the first occluder decides a shadow ray.
-template <bool LOOSE, bool MESH, bool GLASS>
+// GENERAL: planes, or entities with other transforms than one translation (S.general_entities); scenes of
+// plainly placed spheres and meshes run without that code (weekend +5 %).
+template <bool LOOSE, bool MESH, bool GLASS, bool GENERAL>
 __global__ void __launch_bounds__(RT_BLOCK, RT_WAVES_PER_SIMD)
 render_kernel(const DevSceneView S, const RenderParams P) {
     extern __shared__ uint32_t lds_stack[];
@@ -700,7 +706,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                     const Word4 m0 = ldw(mw);
                     if (GLASS && m0.u[0] == RT_MAT_DIELECTRIC) {
                         const F3 td = -ldir;
-                        HitRec hr; resolve_hit(S, hp, td, best, hr);
+                        HitRec hr; resolve_hit<GENERAL, MESH>(S, hp, td, best, hr);
                         float nint; F3 outn;
                         const float kr = dielectric_kr(td, hr.normal, ldw(mw + 1).f[0], nint, outn);
                         if (!(kr >= 1.0f)) {
@@ -719,7 +725,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                 if (best.ent == RT_NONE) { sample_col = sample_col + (rw * color_sky(S, rd)); rnode = 0u; state = NEED_PATH; }
                 else {
                     PH(PH_SHADE_PATH_HIT);
-                    HitRec hr; resolve_hit(S, ro, rd, best, hr);
+                    HitRec hr; resolve_hit<GENERAL, MESH>(S, ro, rd, best, hr);
                     const Word4* mw = S.materials[hr.mat_id].w;
                     const Word4 m0 = ldw(mw);
                     // Material::scatter
@@ -1005,9 +1011,9 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                             const Word4 e0 = ldw(ew), e1 = ldw(ew + 1);
                             const uint32_t kind = e1.u[0] & 0xff;
                             F3 eo = wo, ed = wd;
-                            ray_to_entity(S, e0, e1, eo, ed);
+                            ray_to_entity<GENERAL>(S, e0, e1, eo, ed);
                             float t = 0.0f; bool hit = false;
-                            if (kind == RT_HITABLE_SPHERE) {
+                            if ((!GENERAL && !MESH) || kind == RT_HITABLE_SPHERE) {
                                 // intersect_sphere + Sphere::hit, sphere.rs:4-17, 36-39
                                 const float radius = e0.f[3];
                                 const float qa = dot(ed, ed);
@@ -1021,7 +1027,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                                     hit = in0 || in1;
                                     t = (in0 && in1) ? fminf(t0, t1) : (in0 ? t0 : t1);
                                 }
-                            } else if (kind == RT_HITABLE_PLANE) {
+                            } else if (GENERAL && kind == RT_HITABLE_PLANE) {
                                 // intersect_plane + Plane::hit, plane.rs:4-17, 59-70
                                 const Word4* pw = S.planes[e1.u[1]].w;
                                 const Word4 p0 = ldw(pw), p1 = ldw(pw + 1);
@@ -1448,10 +1454,13 @@ int enqueue_accumulate(RtScene* scene, Workspace& ws, const RtSettings* st, cons
         {
             // one instantiation per combination of scene traits (code and per-lane state a scene does not need are compiled out)
             using Kernel = void (*)(const DevSceneView, const RenderParams);
-            static const Kernel kernels[8] = {render_kernel<false, false, false>, render_kernel<false, false, true>, render_kernel<false, true, false>,
-                                              render_kernel<false, true, true>,   render_kernel<true, false, false>, render_kernel<true, false, true>,
-                                              render_kernel<true, true, false>,   render_kernel<true, true, true>};
-            const int which = (scene->view.loose_boxes ? 4 : 0) | (scene->view.mesh_entities ? 2 : 0) | (scene->view.shadow_any_hit ? 0 : 1);
+            static const Kernel kernels[16] = {
+                render_kernel<false, false, false, false>, render_kernel<false, false, true, false>, render_kernel<false, true, false, false>, render_kernel<false, true, true, false>,
+                nullptr, nullptr, nullptr, nullptr,      // (a non-unit rotation axis makes a scene GENERAL)
+                render_kernel<false, false, false, true>,  render_kernel<false, false, true, true>,  render_kernel<false, true, false, true>,  render_kernel<false, true, true, true>,
+                render_kernel<true, false, false, true>,   render_kernel<true, false, true, true>,   render_kernel<true, true, false, true>,   render_kernel<true, true, true, true>};
+            const bool general = scene->view.general_entities || scene->view.loose_boxes;
+            const int which = (general ? 8 : 0) | (scene->view.loose_boxes ? 4 : 0) | (scene->view.mesh_entities ? 2 : 0) | (scene->view.shadow_any_hit ? 0 : 1);
             hipLaunchKernelGGL(kernels[which], dim3((uint32_t)blocks), dim3(RT_BLOCK), scene->lds_bytes, stream, scene->view, P);
         }
         HIP_TRY(hipGetLastError());
@@ -1524,7 +1533,7 @@ RtScene* rt_scene_create(const RtSceneDesc* desc, int device) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { set_error(RT_E_HIP, "hipGetDeviceProperties failed"); return fail(); }
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_kernel<false, true, true>, RT_BLOCK, s->lds_bytes) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_kernel<false, true, true, true>, RT_BLOCK, s->lds_bytes) != hipSuccess || per_cu < 1) per_cu = 1;
     s->grid_blocks = prop.multiProcessorCount * per_cu;
     if (s->shared.init(false)) return fail();
     return s;

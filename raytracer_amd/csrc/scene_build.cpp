@@ -700,6 +700,11 @@ int build_flat_scene(const RtSceneDesc* d, FlatScene& out, std::string& err) {
     v.shadow_any_hit = 1;
     for (uint64_t i = 0; i < n_mat; i++) if (d->materials[i].kind == RT_MAT_DIELECTRIC) v.shadow_any_hit = 0;
     v.mesh_entities = d->mesh_object_count ? 1u : 0u;
+    v.general_entities = 0;
+    for (uint64_t i = 0; i < n_ent; i++) {
+        const RtEntity& e = d->entities[i];
+        if (e.hitable_kind == RT_HITABLE_PLANE || e.translation_count != 1 || e.rotation_count != 0) { v.general_entities = 1; break; }
+    }
     out.materials.resize(n_mat ? n_mat : 1);
     for (uint64_t i = 0; i < n_mat; i++) {
         const RtMaterial& s = d->materials[i]; DevMaterial& m = out.materials[i];
