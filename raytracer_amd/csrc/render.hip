@@ -415,18 +415,20 @@ __device__ __forceinline__ uint32_t map_to_rank(float p, uint32_t length) {     
 
 // Texture::value, texture.rs:11-134 (chains MeshTextureSet -> MeshTexture -> ColorMap
 // and Checker -> leaf unrolled instead of virtual calls)
+// RICH = false: the scene's textures are plain colours and checkers of them only (DevSceneView::rich_shading == 0)
+template <bool RICH = true>
 __device__ __forceinline__ F3 texture_value(const DevSceneView& S, uint32_t tex_id, const HitRec& h) {
     const F3 not_found = f3(1.0f, 0.41f, 0.70f);                                         // texture.rs:124
     const Word4* tw = S.textures[tex_id].w;
     Word4 t0 = ldw(tw);
     uint32_t kind = t0.u[0];
-    if (kind == RT_TEX_MESH_SET) {
+    if (RICH && kind == RT_TEX_MESH_SET) {
         if (h.tex_key < 0 || h.tex_key >= t0.i[2]) return not_found;
         tw = S.textures[S.tex_set_entries[t0.i[1] + h.tex_key]].w;
         t0 = ldw(tw); kind = t0.u[0];
     }
     bool mesh = false; F3 ambient = f3(0, 0, 0), diffuse = f3(0, 0, 0);
-    if (kind == RT_TEX_MESH) {
+    if (RICH && kind == RT_TEX_MESH) {
         diffuse = w3(ldw(tw + 2)); ambient = w3(ldw(tw + 3));
         if (t0.i[1] < 0) return ambient + diffuse;                                       // texture.rs:111-114
         mesh = true;
@@ -439,11 +441,11 @@ __device__ __forceinline__ F3 texture_value(const DevSceneView& S, uint32_t tex_
     }
     F3 v;
     if (kind == RT_TEX_COLOR) v = w3(ldw(tw + 2));
-    else if (kind == RT_TEX_UV_TEST) v = f3(h.u, h.v, 1.0f - h.u - h.v);
-    else if (kind == RT_TEX_XYZ_TEST) {
+    else if (RICH && kind == RT_TEX_UV_TEST) v = f3(h.u, h.v, 1.0f - h.u - h.v);
+    else if (RICH && kind == RT_TEX_XYZ_TEST) {
         const float mx = ldw(tw + 1).f[2];
         v = f3(0.5f + (h.p.x / mx / 2.0f), 0.5f + (h.p.y / mx / 2.0f), 0.5f + (h.p.z / mx / 2.0f));
-    } else if (kind == RT_TEX_COLOR_MAP) {                                               // texture.rs:93-97
+    } else if (RICH && kind == RT_TEX_COLOR_MAP) {                                               // texture.rs:93-97
         const Word4 t1 = ldw(tw + 1);
         const uint32_t width = t0.u[3], height = t1.u[0];
         const uint64_t x = map_to_rank(h.u, width), y = map_to_rank(h.v, height);
@@ -457,13 +459,15 @@ __device__ __forceinline__ F3 texture_value(const DevSceneView& S, uint32_t tex_
 struct LightRec { float t; F3 direction, color; float intensity; };
 
 // LightSource::get_direction_and_intensity, lights.rs:35-49, 87-109, 138-148
+// RICH = false: no lamp (cone) light in the scene
+template <bool RICH = true>
 __device__ __forceinline__ bool light_record(const DevSceneView& S, uint32_t k, F3 p, LightRec& out) {
     const Word4* lw = S.lights[k].w;
     const Word4 l0 = ldw(lw), l1 = ldw(lw + 1), l2 = ldw(lw + 2), l3 = ldw(lw + 3);
     out.color = w3(l3);
     if (l0.u[0] == RT_LIGHT_DIRECTIONAL) { out.t = RT_F32_MAX; out.direction = w3(l2); out.intensity = l0.f[1]; return true; }
     const F3 direction_to_p = p - w3(l1);
-    if (l0.u[0] == RT_LIGHT_LAMP) {
+    if (RICH && l0.u[0] == RT_LIGHT_LAMP) {
         const F3 lamp = w3(l2);
         const float theta = acosf(dot(direction_to_p, lamp) / (length(direction_to_p) * length(lamp)));   // types.rs:71-75
         const float theta_deg = theta / RT_PI * 180.0f;
@@ -586,7 +590,8 @@ enum { PH_NODE = 0, PH_TRI, PH_ENTITY, PH_SHADE, PH_SHADE_PATH_HIT, PH_SHADE_SHA
 // deferred child rays (the per-lane array in scratch), and the first occluder decides a shadow ray.
 // GENERAL: planes, or entities with other transforms than one translation (S.general_entities); scenes of
 // plainly placed spheres and meshes run without that code (weekend +5 %).
-template <bool LOOSE, bool MESH, bool GLASS, bool GENERAL>
+// RICH: lamp lights, or textures other than colours and checkers (S.rich_shading).
+template <bool LOOSE, bool MESH, bool GLASS, bool GENERAL, bool RICH>
 __global__ void __launch_bounds__(RT_BLOCK, RT_WAVES_PER_SIMD)
 render_kernel(const DevSceneView S, const RenderParams P) {
     extern __shared__ uint32_t lds_stack[];
@@ -711,7 +716,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                         const float kr = dielectric_kr(td, hr.normal, ldw(mw + 1).f[0], nint, outn);
                         if (!(kr >= 1.0f)) {
                             const float refr_intensity = (1.0f - kr) * (1.0f - m0.f[3]);
-                            const F3 albedo = texture_value(S, hr.tex_id, hr);
+                            const F3 albedo = texture_value<RICH>(S, hr.tex_id, hr);
                             lcol = lcol * (albedo * refr_intensity);                          // :541-543
                             closest = best.t + RT_BIAS;
                             state = SHADOW;                                                   // same ray, further on
@@ -762,7 +767,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                     else if (has_refr) refract_limit = rl;
                     const bool cast_refl = has_refl && refl_i > 0.0f, cast_refr = has_refr && refr_i > 0.0f;   // :593, :601
                     const float reflection_intensity = cast_refl ? refl_i : 0.0f, refraction_intensity = cast_refr ? refr_i : 0.0f;
-                    const F3 albedo = texture_value(S, hr.tex_id, hr);                        // :626
+                    const F3 albedo = texture_value<RICH>(S, hr.tex_id, hr);                        // :626
                     wa = rw * albedo;
                     li = fmaxf(0.0f, 1.0f - (reflection_intensity + refraction_intensity));   // :625
                     // children: colour is linear in them, so they carry weight w*albedo*intensity.
@@ -796,7 +801,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                 PH(PH_STAGE_A);
                 while (light_k < S.light_count) {
                     LightRec lr;
-                    if (light_record(S, light_k, hp, lr)) {
+                    if (light_record<RICH>(S, light_k, hp, lr)) {
                         lcol = lr.color * lr.intensity; ldir = lr.direction; l_t = lr.t; closest = RT_BIAS;   // :527-532
                         state = SHADOW;
                         break;
@@ -1454,13 +1459,19 @@ int enqueue_accumulate(RtScene* scene, Workspace& ws, const RtSettings* st, cons
         {
             // one instantiation per combination of scene traits (code and per-lane state a scene does not need are compiled out)
             using Kernel = void (*)(const DevSceneView, const RenderParams);
-            static const Kernel kernels[16] = {
-                render_kernel<false, false, false, false>, render_kernel<false, false, true, false>, render_kernel<false, true, false, false>, render_kernel<false, true, true, false>,
-                nullptr, nullptr, nullptr, nullptr,      // (a non-unit rotation axis makes a scene GENERAL)
-                render_kernel<false, false, false, true>,  render_kernel<false, false, true, true>,  render_kernel<false, true, false, true>,  render_kernel<false, true, true, true>,
-                render_kernel<true, false, false, true>,   render_kernel<true, false, true, true>,   render_kernel<true, true, false, true>,   render_kernel<true, true, true, true>};
+            // index bits: 16 rich shading, 8 general entities, 4 loose boxes, 2 mesh instances, 1 dielectrics
+#define RT_K(L, M, G, N, R) render_kernel<L, M, G, N, R>
+#define RT_K4(L, N, R) RT_K(L, false, false, N, R), RT_K(L, false, true, N, R), RT_K(L, true, false, N, R), RT_K(L, true, true, N, R)
+            static const Kernel kernels[32] = {
+                RT_K4(false, false, false), nullptr, nullptr, nullptr, nullptr,      // (a non-unit rotation axis makes a scene GENERAL)
+                RT_K4(false, true, false),  RT_K4(true, true, false),
+                RT_K4(false, false, true),  nullptr, nullptr, nullptr, nullptr,
+                RT_K4(false, true, true),   RT_K4(true, true, true)};
+#undef RT_K4
+#undef RT_K
             const bool general = scene->view.general_entities || scene->view.loose_boxes;
-            const int which = (general ? 8 : 0) | (scene->view.loose_boxes ? 4 : 0) | (scene->view.mesh_entities ? 2 : 0) | (scene->view.shadow_any_hit ? 0 : 1);
+            const int which = (scene->view.rich_shading ? 16 : 0) | (general ? 8 : 0) | (scene->view.loose_boxes ? 4 : 0) | (scene->view.mesh_entities ? 2 : 0) |
+                              (scene->view.shadow_any_hit ? 0 : 1);
             hipLaunchKernelGGL(kernels[which], dim3((uint32_t)blocks), dim3(RT_BLOCK), scene->lds_bytes, stream, scene->view, P);
         }
         HIP_TRY(hipGetLastError());
@@ -1533,7 +1544,7 @@ RtScene* rt_scene_create(const RtSceneDesc* desc, int device) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { set_error(RT_E_HIP, "hipGetDeviceProperties failed"); return fail(); }
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_kernel<false, true, true, true>, RT_BLOCK, s->lds_bytes) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_kernel<false, true, true, true, true>, RT_BLOCK, s->lds_bytes) != hipSuccess || per_cu < 1) per_cu = 1;
     s->grid_blocks = prop.multiProcessorCount * per_cu;
     if (s->shared.init(false)) return fail();
     return s;

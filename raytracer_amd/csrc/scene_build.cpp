@@ -700,6 +700,9 @@ int build_flat_scene(const RtSceneDesc* d, FlatScene& out, std::string& err) {
     v.shadow_any_hit = 1;
     for (uint64_t i = 0; i < n_mat; i++) if (d->materials[i].kind == RT_MAT_DIELECTRIC) v.shadow_any_hit = 0;
     v.mesh_entities = d->mesh_object_count ? 1u : 0u;
+    v.rich_shading = 0;
+    for (uint64_t i = 0; i < d->light_count; i++) if (d->lights[i].kind == RT_LIGHT_LAMP) v.rich_shading = 1;
+    for (uint64_t i = 0; i < n_tex; i++) if (d->textures[i].kind != RT_TEX_COLOR && d->textures[i].kind != RT_TEX_CHECKER) v.rich_shading = 1;
     v.general_entities = 0;
     for (uint64_t i = 0; i < n_ent; i++) {
         const RtEntity& e = d->entities[i];
