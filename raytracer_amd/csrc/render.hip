@@ -178,13 +178,13 @@ __device__ __forceinline__ void slab2(const Word4& a, const Word4& b, const Word
 }
 
 // Entity::hit's world -> entity ray transform, implementation.rs:288-294
-// GENERAL = false: the scene has no plane and every entity has exactly one translation and no rotation
-// (DevSceneView::general_entities == 0), so only the inline translation is ever needed.
-template <bool GENERAL = true>
+// XFORMS = false: every entity of the scene has exactly one translation and no rotation
+// (DevSceneView::general_xforms == 0), so only the inline translation is ever needed.
+template <bool XFORMS = true>
 __device__ __forceinline__ void ray_to_entity(const DevSceneView& S, const Word4& e0, const Word4& e1, F3& o, F3& d) {
     const uint32_t packed = e1.u[0];
     const uint32_t n_trans = (packed >> 8) & 0xff, n_rot = (packed >> 16) & 0xff;
-    if (!GENERAL || (n_trans == 1 && n_rot == 0)) { o = o - w3(e0); return; }     // translation kept inline
+    if (!XFORMS || (n_trans == 1 && n_rot == 0)) { o = o - w3(e0); return; }     // translation kept inline
     const Word4* x = S.xforms + e1.u[2];
     for (uint32_t k = 0; k < n_trans; k++) o = o - w3(ldw(x + k));
     x += n_trans;
@@ -344,19 +344,20 @@ __device__ __forceinline__ void trace(const DevSceneView& S, const F3 wo, const 
 // ===========================================================================
 struct HitRec { F3 p, normal; float u, v; uint32_t mat_id, tex_id; int32_t tex_key; int32_t entity_index, tri_index; };
 
-template <bool GENERAL = true, bool MESH = true>
+// MESH / SPHERES / PLANES: the kinds of hitable the scene has
+template <bool XFORMS = true, bool MESH = true, bool SPHERES = true, bool PLANES = true>
 __device__ __forceinline__ void resolve_hit(const DevSceneView& S, F3 o, F3 d, const Hit& h, HitRec& r) {
     const Word4* ew = S.entities[h.ent].w;
     const Word4 e0 = ldw(ew), e1 = ldw(ew + 1), e2 = ldw(ew + 2);
     const uint32_t kind = e1.u[0] & 0xff;
-    ray_to_entity<GENERAL>(S, e0, e1, o, d);
+    ray_to_entity<XFORMS>(S, e0, e1, o, d);
     r.mat_id = e1.u[3]; r.tex_id = e2.u[0]; r.entity_index = (int32_t)e2.u[1]; r.tex_key = -1; r.tri_index = -1;
     const float t = h.t;
     F3 p = o + (d * t), normal;
     r.u = 0.0f; r.v = 0.0f;
-    if ((!GENERAL && !MESH) || kind == RT_HITABLE_SPHERE) {
+    if (SPHERES && ((!MESH && !PLANES) || kind == RT_HITABLE_SPHERE)) {
         normal = unit(p / e0.f[3]);                                              // sphere.rs:40-41
-    } else if (GENERAL && kind == RT_HITABLE_PLANE) {
+    } else if (PLANES && (!MESH || kind == RT_HITABLE_PLANE)) {
         const Word4* pw = S.planes[e1.u[1]].w;
         const Word4 p0 = ldw(pw), p1 = ldw(pw + 1), p2 = ldw(pw + 2);
         const F3 pn = w3(p0);
@@ -381,7 +382,7 @@ __device__ __forceinline__ void resolve_hit(const DevSceneView& S, F3 o, F3 d, c
     }
     // implementation.rs:300-306: rotations reversed (+theta), then translations reversed
     const uint32_t n_trans = (e1.u[0] >> 8) & 0xff, n_rot = (e1.u[0] >> 16) & 0xff;
-    if (!GENERAL || (n_trans == 1 && n_rot == 0)) p = p + w3(e0);
+    if (!XFORMS || (n_trans == 1 && n_rot == 0)) p = p + w3(e0);
     else {
         const Word4* x = S.xforms + e1.u[2];
         for (uint32_t k = n_rot; k-- > 0;) {
@@ -582,16 +583,16 @@ enum { PH_NODE = 0, PH_TRI, PH_ENTITY, PH_SHADE, PH_SHADE_PATH_HIT, PH_SHADE_SHA
 #define PH(i) do { } while (0)
 #endif
 
-// LOOSE: the scene has entity boxes that do not bound their hits (device_scene.h, loose_boxes):
-// TLAS boxes are then tested against the ray's whole interval, as the reference does for every box.
-// MESH: the scene has mesh instances (MESH); scenes of spheres and planes only run an instantiation
-// without the BLAS code and its per-lane state (weekend +4 %).
-// GLASS: some material is a dielectric (!S.shadow_any_hit); without one there is no refraction, so no
-// deferred child rays (the per-lane array in scratch), and the first occluder decides a shadow ray.
-// GENERAL: planes, or entities with other transforms than one translation (S.general_entities); scenes of
-// plainly placed spheres and meshes run without that code (weekend +5 %).
+// The kernel is instantiated per combination of scene traits, and a scene runs the instantiation without the
+// code and per-lane state it does not need (register pressure is what limits this kernel: weekend +18 %,
+// Dreadnaught +4 % over the one-size kernel):
+// LOOSE: the scene has entity boxes that do not bound their hits (device_scene.h, loose_boxes): TLAS boxes are
+//   then tested against the ray's whole interval, as the reference does for every box (one instantiation,
+//   with everything else enabled);
+// MESH / SPHERES / PLANES: kinds of hitable among the entities (MESH: the BLAS walk and its state);
+// XFORMS: entities with other transforms than exactly one translation (S.general_xforms);
 // RICH: lamp lights, or textures other than colours and checkers (S.rich_shading).
-template <bool LOOSE, bool MESH, bool GLASS, bool GENERAL, bool RICH>
+template <bool LOOSE, bool MESH, bool SPHERES, bool PLANES, bool XFORMS, bool RICH>
 __global__ void __launch_bounds__(RT_BLOCK, RT_WAVES_PER_SIMD)
 render_kernel(const DevSceneView S, const RenderParams P) {
     extern __shared__ uint32_t lds_stack[];
@@ -642,7 +643,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
     // scene_build.cpp) are read from LDS instead of through the vector memory path: the texture
     // addresser is 70-80 % busy with the gathers of this kernel (18 cycles per wave instruction), and
     // every ray walks the top levels (weekend +6 %).
-    uint32_t* const node_cache = lds_stack + (stack_cap + (MESH ? 3u : 0u)) * RT_BLOCK;      // (three rows park 1/d while a lane is inside an instance)
+    uint32_t* const node_cache = lds_stack + (stack_cap + (S.mesh_entities ? 3u : 0u)) * RT_BLOCK;      // (three rows park 1/d while a lane is inside an instance; sized by the SCENE, rt_scene_create)
     for (uint32_t i = threadIdx.x; i < S.lds_nodes * 4u; i += RT_BLOCK) {
         const float4 v = *reinterpret_cast<const float4*>(&S.nodes[i >> 2].w[i & 3u]);
         *reinterpret_cast<float4*>(node_cache + (i >> 2) * (RT_NODE_CACHE_STRIDE / 4u) + (i & 3u) * 4u) = v;
@@ -709,9 +710,9 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                     const uint32_t mat_id = ldw(S.entities[best.ent].w + 1).u[3];
                     const Word4* mw = S.materials[mat_id].w;
                     const Word4 m0 = ldw(mw);
-                    if (GLASS && m0.u[0] == RT_MAT_DIELECTRIC) {
+                    if (m0.u[0] == RT_MAT_DIELECTRIC) {
                         const F3 td = -ldir;
-                        HitRec hr; resolve_hit<GENERAL, MESH>(S, hp, td, best, hr);
+                        HitRec hr; resolve_hit<XFORMS, MESH, SPHERES, PLANES>(S, hp, td, best, hr);
                         float nint; F3 outn;
                         const float kr = dielectric_kr(td, hr.normal, ldw(mw + 1).f[0], nint, outn);
                         if (!(kr >= 1.0f)) {
@@ -730,7 +731,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                 if (best.ent == RT_NONE) { sample_col = sample_col + (rw * color_sky(S, rd)); rnode = 0u; state = NEED_PATH; }
                 else {
                     PH(PH_SHADE_PATH_HIT);
-                    HitRec hr; resolve_hit<GENERAL, MESH>(S, ro, rd, best, hr);
+                    HitRec hr; resolve_hit<XFORMS, MESH, SPHERES, PLANES>(S, ro, rd, best, hr);
                     const Word4* mw = S.materials[hr.mat_id].w;
                     const Word4 m0 = ldw(mw);
                     // Material::scatter
@@ -749,7 +750,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                             scattered = reflected + (unit(random_normal_reflection_angle(hr.normal, r0, r1)) * m0.f[2]);
                         }
                         if (dot(scattered, hr.normal) > 0.0f) { has_refl = true; refl_d = scattered; refl_i = m0.f[1]; }
-                    } else if (GLASS) {                                                       // materials.rs:167-204
+                    } else {                                                                  // materials.rs:167-204
                         float ni_over_nt; F3 outward_normal;
                         const float kr = dielectric_kr(rd, hr.normal, ldw(mw + 1).f[0], ni_over_nt, outward_normal);
                         if (!(kr >= 1.0f)) {
@@ -910,7 +911,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                 o = shadow ? hp : ro;
                 d = shadow ? -ldir : rd;
                 inv = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-                if (MESH) {      // read back when the walk leaves an instance (three divisions saved per exit)
+                if (MESH && S.mesh_entities) {      // read back when the walk leaves an instance (three divisions saved per exit)
                     stack[stack_cap * RT_BLOCK] = __float_as_uint(inv.x); stack[(stack_cap + 1u) * RT_BLOCK] = __float_as_uint(inv.y);
                     stack[(stack_cap + 2u) * RT_BLOCK] = __float_as_uint(inv.z);
                 }
@@ -1016,9 +1017,9 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                             const Word4 e0 = ldw(ew), e1 = ldw(ew + 1);
                             const uint32_t kind = e1.u[0] & 0xff;
                             F3 eo = wo, ed = wd;
-                            ray_to_entity<GENERAL>(S, e0, e1, eo, ed);
+                            ray_to_entity<XFORMS>(S, e0, e1, eo, ed);
                             float t = 0.0f; bool hit = false;
-                            if ((!GENERAL && !MESH) || kind == RT_HITABLE_SPHERE) {
+                            if (SPHERES && ((!MESH && !PLANES) || kind == RT_HITABLE_SPHERE)) {
                                 // intersect_sphere + Sphere::hit, sphere.rs:4-17, 36-39
                                 const float radius = e0.f[3];
                                 const float qa = dot(ed, ed);
@@ -1032,7 +1033,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                                     hit = in0 || in1;
                                     t = (in0 && in1) ? fminf(t0, t1) : (in0 ? t0 : t1);
                                 }
-                            } else if (GENERAL && kind == RT_HITABLE_PLANE) {
+                            } else if (PLANES && (!MESH || kind == RT_HITABLE_PLANE)) {
                                 // intersect_plane + Plane::hit, plane.rs:4-17, 59-70
                                 const Word4* pw = S.planes[e1.u[1]].w;
                                 const Word4 p0 = ldw(pw), p1 = ldw(pw + 1);
@@ -1071,7 +1072,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                     }
                 }
                 // a shadow ray of a scene without dielectrics is decided by ANY occluder
-                if (!GLASS && state == SHADOW && best.ent != RT_NONE) cur = RT_NONE;
+                if (S.shadow_any_hit && state == SHADOW && best.ent != RT_NONE) cur = RT_NONE;
                 if (cur == RT_NONE) tracing = false;      // closest hit (or miss) is in `best`
             }
             // leave the burst when enough lanes can take a new ray, or nobody is tracing
@@ -1459,20 +1460,19 @@ int enqueue_accumulate(RtScene* scene, Workspace& ws, const RtSettings* st, cons
         {
             // one instantiation per combination of scene traits (code and per-lane state a scene does not need are compiled out)
             using Kernel = void (*)(const DevSceneView, const RenderParams);
-            // index bits: 16 rich shading, 8 general entities, 4 loose boxes, 2 mesh instances, 1 dielectrics
-#define RT_K(L, M, G, N, R) render_kernel<L, M, G, N, R>
-#define RT_K4(L, N, R) RT_K(L, false, false, N, R), RT_K(L, false, true, N, R), RT_K(L, true, false, N, R), RT_K(L, true, true, N, R)
-            static const Kernel kernels[32] = {
-                RT_K4(false, false, false), nullptr, nullptr, nullptr, nullptr,      // (a non-unit rotation axis makes a scene GENERAL)
-                RT_K4(false, true, false),  RT_K4(true, true, false),
-                RT_K4(false, false, true),  nullptr, nullptr, nullptr, nullptr,
-                RT_K4(false, true, true),   RT_K4(true, true, true)};
-#undef RT_K4
+            // index bits: 1 mesh instances, 2 spheres, 4 planes, 8 general transforms, 16 rich shading
+#define RT_K(M, S_, P_, X, R) render_kernel<false, M, S_, P_, X, R>
+#define RT_K8(X, R) nullptr, RT_K(true, false, false, X, R), RT_K(false, true, false, X, R), RT_K(true, true, false, X, R), \
+                    RT_K(false, false, true, X, R), RT_K(true, false, true, X, R), RT_K(false, true, true, X, R), RT_K(true, true, true, X, R)
+            static const Kernel kernels[32] = {RT_K8(false, false), RT_K8(true, false), RT_K8(false, true), RT_K8(true, true)};
+#undef RT_K8
 #undef RT_K
-            const bool general = scene->view.general_entities || scene->view.loose_boxes;
-            const int which = (scene->view.rich_shading ? 16 : 0) | (general ? 8 : 0) | (scene->view.loose_boxes ? 4 : 0) | (scene->view.mesh_entities ? 2 : 0) |
-                              (scene->view.shadow_any_hit ? 0 : 1);
-            hipLaunchKernelGGL(kernels[which], dim3((uint32_t)blocks), dim3(RT_BLOCK), scene->lds_bytes, stream, scene->view, P);
+            const DevSceneView& v = scene->view;
+            int which = (v.mesh_entities ? 1 : 0) | (v.sphere_entities ? 2 : 0) | (v.plane_entities ? 4 : 0) | (v.general_xforms ? 8 : 0) | (v.rich_shading ? 16 : 0);
+            if ((which & 7) == 0) which |= 2;                                        // (an empty scene: any instantiation will do)
+            if (getenv("RT_DEBUG_TRAITS")) fprintf(stderr, "traits: which=%d loose=%u any_hit=%u lds_nodes=%u\n", which, v.loose_boxes, v.shadow_any_hit, v.lds_nodes);
+            const Kernel kernel = v.loose_boxes ? render_kernel<true, true, true, true, true, true> : kernels[which];
+            hipLaunchKernelGGL(kernel, dim3((uint32_t)blocks), dim3(RT_BLOCK), scene->lds_bytes, stream, scene->view, P);
         }
         HIP_TRY(hipGetLastError());
 #ifdef RT_PHASE_STATS
@@ -1544,7 +1544,7 @@ RtScene* rt_scene_create(const RtSceneDesc* desc, int device) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { set_error(RT_E_HIP, "hipGetDeviceProperties failed"); return fail(); }
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_kernel<false, true, true, true, true>, RT_BLOCK, s->lds_bytes) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_kernel<true, true, true, true, true, true>, RT_BLOCK, s->lds_bytes) != hipSuccess || per_cu < 1) per_cu = 1;
     s->grid_blocks = prop.multiProcessorCount * per_cu;
     if (s->shared.init(false)) return fail();
     return s;

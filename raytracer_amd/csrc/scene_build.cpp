@@ -703,10 +703,12 @@ int build_flat_scene(const RtSceneDesc* d, FlatScene& out, std::string& err) {
     v.rich_shading = 0;
     for (uint64_t i = 0; i < d->light_count; i++) if (d->lights[i].kind == RT_LIGHT_LAMP) v.rich_shading = 1;
     for (uint64_t i = 0; i < n_tex; i++) if (d->textures[i].kind != RT_TEX_COLOR && d->textures[i].kind != RT_TEX_CHECKER) v.rich_shading = 1;
-    v.general_entities = 0;
+    v.general_xforms = v.sphere_entities = v.plane_entities = 0;
     for (uint64_t i = 0; i < n_ent; i++) {
         const RtEntity& e = d->entities[i];
-        if (e.hitable_kind == RT_HITABLE_PLANE || e.translation_count != 1 || e.rotation_count != 0) { v.general_entities = 1; break; }
+        if (e.hitable_kind == RT_HITABLE_SPHERE) v.sphere_entities = 1;
+        if (e.hitable_kind == RT_HITABLE_PLANE) v.plane_entities = 1;
+        if (e.translation_count != 1 || e.rotation_count != 0) v.general_xforms = 1;
     }
     out.materials.resize(n_mat ? n_mat : 1);
     for (uint64_t i = 0; i < n_mat; i++) {
