@@ -1470,7 +1470,8 @@ int enqueue_accumulate(RtScene* scene, Workspace& ws, const RtSettings* st, cons
             const DevSceneView& v = scene->view;
             int which = (v.mesh_entities ? 1 : 0) | (v.sphere_entities ? 2 : 0) | (v.plane_entities ? 4 : 0) | (v.general_xforms ? 8 : 0) | (v.rich_shading ? 16 : 0);
             if ((which & 7) == 0) which |= 2;                                        // (an empty scene: any instantiation will do)
-            if (getenv("RT_DEBUG_TRAITS")) fprintf(stderr, "traits: which=%d loose=%u any_hit=%u lds_nodes=%u\n", which, v.loose_boxes, v.shadow_any_hit, v.lds_nodes);
+            static const bool show_traits = getenv("RT_DEBUG_TRAITS") != nullptr;      // diagnostics: which instantiation a scene runs
+            if (show_traits) fprintf(stderr, "traits: which=%d loose=%u any_hit=%u lds_nodes=%u\n", which, v.loose_boxes, v.shadow_any_hit, v.lds_nodes);
             const Kernel kernel = v.loose_boxes ? render_kernel<true, true, true, true, true, true> : kernels[which];
             hipLaunchKernelGGL(kernel, dim3((uint32_t)blocks), dim3(RT_BLOCK), scene->lds_bytes, stream, scene->view, P);
         }
