@@ -106,12 +106,21 @@ class InterleavedCompositor:
         self.rows = [strip_rows(height, strip_height, r, world) for r in range(world)]
         assert sum(self.rows) == height
         self.my_rows = self.rows[rank]
-        self.packed = torch.zeros((max(max(self.rows), 1), width, channels), dtype=dtype, device=device)
-        self.gathered = ([torch.zeros_like(self.packed) for _ in range(world)] if rank == dst and world > 1 else None)
-        self.frame = torch.zeros((height, width, channels), dtype=dtype, device=device) if rank == dst else None
-        self.row_index = None
+        max_rows = max(max(self.rows), 1)
+        self.packed = torch.zeros((max_rows, width, channels), dtype=dtype, device=device)
+        self.gathered = self.frame = self.row_index = None
         if rank == dst:
-            self.row_index = [torch.tensor(self.image_rows(r), dtype=torch.long, device=device) for r in range(world)]
+            # One receive buffer for all ranks and ONE scatter per frame: row k of rank r goes to its image row,
+            # the padding rows of ranks with fewer rows go to a spare row below the frame.
+            self._all = torch.zeros((world, max_rows, width, channels), dtype=dtype, device=device)
+            self.gathered = [self._all[r] for r in range(world)] if world > 1 else None
+            self._frame_ext = torch.zeros((height + 1, width, channels), dtype=dtype, device=device)
+            self.frame = self._frame_ext[:height]
+            index = []
+            for r in range(world):
+                rows = self.image_rows(r)
+                index.extend(rows + [height] * (max_rows - len(rows)))
+            self.row_index = torch.tensor(index, dtype=torch.long, device=device)
 
     def image_rows(self, r):
         """Image row of every packed local row of rank r."""
@@ -123,14 +132,16 @@ class InterleavedCompositor:
         return out
 
     def composite(self):
-        sources = [self.packed]
+        got = None
         if self.world > 1:
-            sources = _gather(self.packed, self.gathered, self.dst, self.rank, self.world)
+            got = _gather(self.packed, self.gathered, self.dst, self.rank, self.world)
         if self.rank != self.dst:
             return None
-        for r in range(self.world):
-            if self.rows[r]:
-                self.frame.index_copy_(0, self.row_index[r], sources[r][:self.rows[r]])
+        if got is not None and got is not self.gathered:       # (the all_gather fallback brings its own buffers)
+            for r in range(self.world):
+                self._all[r].copy_(got[r])
+        src = self._all if self.world > 1 else self.packed.unsqueeze(0)
+        self._frame_ext.index_copy_(0, self.row_index, src.reshape(-1, self.width, src.shape[-1]))
         return self.frame
 
 
