@@ -528,6 +528,8 @@ struct RenderParams {
     uint32_t unit_len;                              // samples per work item: RT_SAMPLE_SEGMENT (coarse) or 1 (fine)
     uint32_t unit_first, unit_count;                // units (absolute index = sample / unit_len) covered by this launch
     uint32_t round_units_shift;                     // log2 of the units whose samples share a round (divides unit_count)
+    float lens_coc_px;                              // classify_kernel: circle of confusion (pixels) from which a tile's rounds go by lens cell
+    uint32_t lens_rounds;                           // tiles flagged by classify_kernel may run rounds of one sample index (8 units x 8 pixels)
     uint32_t tiles_x, pix_slots;                    // 8x8 tiling of the chunk; pix_slots = tiles*64
     float* partial;                                 // [unit_count][tile][64][3] sums of the clamped samples of each unit (8x8 tiles of the chunk)
     unsigned long long* counters;                   // RtRayCounters on the device (nullable)
@@ -620,7 +622,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
     bool tracing = false;
     uint32_t pxy = 0, s = RT_NONE;           // pixel (x | y << 16) and sample index of the lane's current round (RT_NONE: no sample)
     // the wave's current block (wave-uniform): tile, unit, rounds started
-    uint32_t blk_tile = 0, blk_unit = 0, round_next = 0;
+    uint32_t blk_tile = 0, blk_unit = 0, round_next = 0, blk_lens = 0;
     uint32_t blk_xy0 = 0, blk_py0 = 0;          // the tile's first pixel: chunk-local x | y << 16, and its image row
     F3 sample_col = f3(0, 0, 0);
     Pending pend[RT_PENDING_MAX]; uint32_t npend = 0;
@@ -678,7 +680,9 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                     uint32_t tile_rank, unit_local;
                     if (blk < heavy_blocks) { tile_rank = blk / P.unit_count; unit_local = blk % P.unit_count; }
                     else { const uint32_t b = blk - heavy_blocks, rest = n_tiles - heavy; unit_local = b / rest; tile_rank = heavy + b % rest; }
-                    blk_tile = P.tile_order ? P.tile_order[tile_rank] : tile_rank;
+                    blk_tile = P.tile_order ? P.tile_order[tile_rank] : tile_rank;      // bit 31: the tile's rounds go by lens cell
+                    blk_lens = P.lens_rounds ? blk_tile >> 31 : 0u;
+                    blk_tile &= 0x7fffffffu;
                     {
                         const uint32_t x0 = (blk_tile % P.tiles_x) * 8u, y0 = (blk_tile / P.tiles_x) * 8u;
                         blk_xy0 = x0 | (y0 << 16);
@@ -846,9 +850,10 @@ render_kernel(const DevSceneView S, const RenderParams P) {
         if (__ballot(tracing || state != NEED_SAMPLE) == 0ull) {        // wave-uniform: every lane has finished its sample
             // lane = (unit of the group, sample of the unit, pixel of the round); all sizes are powers of two
             const uint32_t l_shift = P.unit_len == 1u ? 0u : RT_SEGMENT_SHIFT, k_shift = P.round_units_shift;
-            const uint32_t g_shift = 6u - l_shift - k_shift;                    // log2(pixels per round)
+            const bool lens = blk_lens != 0u;
+            const uint32_t g_shift = lens ? 3u : 6u - l_shift - k_shift;                    // log2(pixels per round)
             const uint32_t q = lane & ((1u << g_shift) - 1u), j = lane >> g_shift;
-            const uint32_t u_in = j >> l_shift, jj = j & (P.unit_len - 1u);
+            const uint32_t u_in = lens ? j : j >> l_shift, jj = lens ? 0u : j & (P.unit_len - 1u);
             const uint32_t sub = blk_unit & ((1u << k_shift) - 1u), unit_local = ((blk_unit >> k_shift) << k_shift) + u_in;
             const uint32_t x0 = blk_xy0 & 0xffffu, y0 = blk_xy0 >> 16;
             const uint32_t s_mine = (P.unit_first + unit_local) * P.unit_len + jj;
@@ -856,7 +861,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
             // pixel of this lane in round g: Z-order inside the tile, so that the pixels of a round and of a
             // block form compact rectangles (8 -> 4x2, 4 -> 2x2, 2 -> 2x1)
             auto round_pixel = [&](uint32_t g, uint32_t& x, uint32_t& y) {
-                const uint32_t z = (sub << (6u - k_shift)) + (g << g_shift) + q;
+                const uint32_t z = lens ? (sub << 3) + q : (sub << (6u - k_shift)) + (g << g_shift) + q;
                 x = (z & 1u) | ((z >> 1) & 2u) | ((z >> 2) & 4u);
                 y = ((z >> 1) & 1u) | ((z >> 2) & 2u) | ((z >> 3) & 4u);
             };
@@ -866,7 +871,8 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                     const F3 c = s != RT_NONE ? sample_col : f3(0.0f, 0.0f, 0.0f);     // (x + 0 == x: the sum is never -0)
                     F3 sum = f3(0.0f, 0.0f, 0.0f);
                     static_assert(RT_SAMPLE_SEGMENT == 8u, "seq_sum8 adds the 8 samples of a segment");
-                    if (l_shift != 0u && g_shift == 0u) sum = f3(seq_sum8<1>(c.x), seq_sum8<1>(c.y), seq_sum8<1>(c.z));          // the unit's samples: 8 consecutive lanes
+                    if (lens) sum = c;             // (a lane owns one pixel of one unit: its sum is carried in the output slot, below)
+                    else if (l_shift != 0u && g_shift == 0u) sum = f3(seq_sum8<1>(c.x), seq_sum8<1>(c.y), seq_sum8<1>(c.z));          // the unit's samples: 8 consecutive lanes
                     else if (l_shift != 0u && g_shift == 1u) sum = f3(seq_sum8<2>(c.x), seq_sum8<2>(c.y), seq_sum8<2>(c.z));     // every second lane
                     else for (uint32_t k = 0; k < P.unit_len; k++) {
                         const int src = (int)(((((u_in << l_shift) + k)) << g_shift) | q);
@@ -875,12 +881,18 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                     uint32_t x, y; round_pixel(round_next - 1u, x, y);
                     if (jj == 0u && x0 + x < P.cw && y0 + y < P.ch) {
                         float* out = P.partial + ((uint64_t)(unit_local * (P.pix_slots >> 6) + blk_tile) * 64u + (y * 8u + x)) * 3;
+                        if (lens) {                // ((0 + c0) + c1) + ...: the same additions, one per round
+                            const F3 acc = round_next == 1u ? f3(0.0f, 0.0f, 0.0f) : f3(out[0], out[1], out[2]);
+                            sum = acc + sum;
+                        }
                         out[0] = sum.x; out[1] = sum.y; out[2] = sum.z;
                     }
                 }
                 if (round_next == P.unit_len) { state = NEED_BLOCK; break; }      // wait for the wave's next block
                 uint32_t x, y; round_pixel(round_next, x, y);
                 round_next++;
+                if (lens) { const uint32_t sl = s_mine + (round_next - 1u); s = (x0 + x < P.cw && y0 + y < P.ch && sl >= P.sample_first && sl < P.sample_first + P.sample_count) ? sl : RT_NONE; }
+                else
                 s = (x0 + x < P.cw && y0 + y < P.ch && s_ok) ? s_mine : RT_NONE;      // lanes off the chunk's edge sit the round out
                 if (s != RT_NONE) {
                     PH(PH_STAGE_C);
@@ -890,6 +902,14 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                     float lx = 0.0f, ly = 0.0f;
                     if (P.spp > 1) {                                                  // :648-653
                         float r0, r1; rng_pair(P.seed, pxy, s, 0u, PURPOSE_LENS, r0, r1);
+                        // Lens samples are stratified inside every complete segment: sample s in cell s mod 8 of a
+                        // 4 x 2 grid over the lens square, jittered inside the cell (the reference draws them
+                        // independently: same expectation, less noise - and the rays of one sample index of
+                        // neighbouring pixels leave the lens close together, see the round shapes above).
+                        if (((s >> RT_SEGMENT_SHIFT) + 1u) * RT_SAMPLE_SEGMENT <= P.spp) {
+                            const uint32_t cell = s & 7u;
+                            r0 = ((float)(cell & 3u) + r0) * 0.25f; r1 = ((float)(cell >> 2) + r1) * 0.5f;
+                        }
                         lx = r0 * 2.0f - 1.0f; ly = r1 * 2.0f - 1.0f;
                     }
                     gen_camera_ray(S, pu, pv, lx, ly, ro, rd);
@@ -1177,6 +1197,7 @@ classify_kernel(const DevSceneView S, const RenderParams P, uint32_t n_tiles, ui
     const uint32_t tl = live ? tile : 0u;
     const uint32_t x = (tl % P.tiles_x) * 8u + 2u * (k & 3u) + ((k >> 2) & 1u), y = (tl / P.tiles_x) * 8u + 2u * (k >> 2) + (k & 1u);
     uint32_t cls = 3u;
+    float coc = 0.0f, hits = 0.0f;
     if (live && x < P.cw && y < P.ch) {
         const uint32_t px = P.left + x;
         const uint32_t py = P.strip_h ? P.strip_first_row + (y / P.strip_h) * P.strip_period_rows + (y % P.strip_h) : P.top + y;
@@ -1188,10 +1209,20 @@ classify_kernel(const DevSceneView S, const RenderParams P, uint32_t n_tiles, ui
         if (h.ent != RT_NONE) {
             const Word4 m0 = ldw(S.materials[ldw(S.entities[h.ent].w + 1).u[3]].w);
             cls = m0.u[0] == RT_MAT_DIELECTRIC ? 0u : ((m0.u[0] == RT_MAT_SPECULAR || m0.f[1] > 0.0f) ? 1u : 2u);
+            // circle of confusion at the hit, in pixels: camera rays meet the focal plane at t = 1 (Camera::get_ray,
+            // :482-491), rays of one pixel are 2 R |1 - t| apart at t, a pixel is t |horizontal| / width wide there
+            coc = 2.0f * S.cam_lens_radius * fabsf(1.0f - h.t) * (float)P.width / (h.t * length(ld3(S.cam_horizontal)));
+            hits = 1.0f;
         }
     }
-    for (int off = 8; off > 0; off >>= 1) { const uint32_t other = (uint32_t)__shfl_xor((int)cls, off, 64); cls = other < cls ? other : cls; }
-    if (live && k == 0u) tile_bin[tile] = cls;
+    for (int off = 8; off > 0; off >>= 1) {
+        const uint32_t other = (uint32_t)__shfl_xor((int)cls, off, 64); cls = other < cls ? other : cls;
+        coc += __shfl_xor(coc, off, 64); hits += __shfl_xor(hits, off, 64);
+    }
+    // Round shape of the tile (render_kernel): where the rays of a pixel spread over more than P.lens_coc_px pixels,
+    // rounds of one sample index (one lens cell) of 8 neighbouring pixels are more coherent than rounds of one pixel.
+    const uint32_t by_lens = (hits > 0.0f && coc > P.lens_coc_px * hits) ? 0x100u : 0u;
+    if (live && k == 0u) tile_bin[tile] = cls | by_lens;
 }
 
 // Stable counting sort of the tiles by class (row-major order kept inside a class, so that waves
@@ -1203,7 +1234,7 @@ order_kernel(const uint32_t* tile_bin, uint32_t n_tiles, uint32_t* tile_order) {
     const uint32_t t = threadIdx.x, per = (n_tiles + 1023u) / 1024u;
     const uint32_t lo = t * per < n_tiles ? t * per : n_tiles, hi = lo + per < n_tiles ? lo + per : n_tiles;
     uint32_t mine[RT_COST_BINS] = {0u, 0u, 0u, 0u};
-    for (uint32_t i = lo; i < hi; i++) mine[tile_bin[i]]++;
+    for (uint32_t i = lo; i < hi; i++) mine[tile_bin[i] & 0xffu]++;
     for (uint32_t b = 0; b < RT_COST_BINS; b++) counts[t][b] = mine[b];
     __syncthreads();
     if (t < RT_COST_BINS) {                            // exclusive scan over the threads, per class
@@ -1220,7 +1251,7 @@ order_kernel(const uint32_t* tile_bin, uint32_t n_tiles, uint32_t* tile_order) {
     __syncthreads();
     uint32_t pos[RT_COST_BINS];
     for (uint32_t b = 0; b < RT_COST_BINS; b++) pos[b] = class_base[b] + counts[t][b];
-    for (uint32_t i = lo; i < hi; i++) tile_order[pos[tile_bin[i]]++] = i;
+    for (uint32_t i = lo; i < hi; i++) { const uint32_t b = tile_bin[i]; tile_order[pos[b & 0xffu]++] = i | ((b >> 8) << 31); }      // bit 31: rounds by lens cell
 }
 
 __global__ void __launch_bounds__(RT_BLOCK)
@@ -1414,6 +1445,8 @@ int enqueue_accumulate(RtScene* scene, Workspace& ws, const RtSettings* st, cons
     P.partial = (float*)ws.partial.p;
     P.counters = counters_dev;
     P.strip_h = il.strip_h; P.strip_period_rows = il.period_rows; P.strip_first_row = il.first_row;
+    // RT_LENS_COC: circle of confusion in pixels from which a tile runs lens-cell rounds (a huge value turns them off)
+    { const char* e = getenv("RT_LENS_COC"); P.lens_coc_px = e ? (float)atof(e) : 4.0f; }      // (4 px measured best; 3..8 within 1 %)
     // expensive tiles first (whole-segment launches over enough tiles to have a tail worth hiding)
     const uint32_t n_tiles = pix_slots / 64;
     static const bool order_tiles = []() { const char* e = getenv("RT_TILE_ORDER"); return !e || atoi(e) != 0; }();
@@ -1440,7 +1473,9 @@ int enqueue_accumulate(RtScene* scene, Workspace& ws, const RtSettings* st, cons
             const int cap = e ? atoi(e) : 8;
             const uint32_t max_shift = cap >= 8 ? 3u : cap >= 4 ? 2u : cap >= 2 ? 1u : 0u;
             P.round_units_shift = 0;
+            P.lens_rounds = P.tile_order != nullptr;          // (whole-segment units over enough tiles: the tiles are classified)
             while (!fine && P.round_units_shift < max_shift && P.unit_count % (2u << P.round_units_shift) == 0) P.round_units_shift++;
+            if (P.round_units_shift != 3u) P.lens_rounds = 0u;
         }
         const uint64_t items = (uint64_t)P.pix_slots * P.unit_count;
         uint64_t blocks = (items + RT_BLOCK - 1) / RT_BLOCK;

@@ -161,6 +161,22 @@ def test_work_split_does_not_change_the_bits(spp, first, count, w, h, monkeypatc
     assert (d.max(axis=2) > 1e-3).mean() < 2e-3 and d.mean() < 1e-4
 
 
+def test_round_shape_does_not_change_the_bits(monkeypatch):
+    """Tiles whose rays spread over many pixels (depth of field) are traced in rounds of one sample index of 8
+    neighbouring pixels, the others in rounds of 64 samples of one pixel; the choice is made per tile from an
+    estimate of the circle of confusion and only changes the schedule."""
+    w, h = 208, 120                     # 26 x 15 tiles: enough for the tiles to be classified
+    b, scene, oracle = make("Random Spheres", w, h)
+    st, ch = RenderSettings(w, h, 6, 64), RenderChunk(0, 0, w, h)
+    out = {}
+    for coc in ("0", "4", "1e9"):       # every tile by lens cell / mixed / none
+        monkeypatch.setenv("RT_LENS_COC", coc)
+        rgb, rgba, cn = scene.render_chunk(st, ch, seed=5)
+        out[coc] = (rgb, cn.rays)
+    assert np.array_equal(out["0"][0], out["1e9"][0]) and np.array_equal(out["4"][0], out["1e9"][0])
+    assert out["0"][1] == out["1e9"][1] == out["4"][1]
+
+
 def test_concurrent_host_threads_render_the_same_frame():
     """rt_render_chunk from several host threads at once (the reference's worker threads, src/render.rs:186-224):
     each call borrows its own workspace and stream; the frame is bit-identical to the one-call frame."""
