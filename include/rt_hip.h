@@ -240,7 +240,11 @@ void     rt_scene_destroy(RtScene* scene);
  *              nullable
  *   seed     : replaces XorShiftRng::seed_from_u64(12345) (render.rs:142) by
  *              the key of a counter-based RNG addressed (seed,x,y,sample,node):
- *              the image does not depend on chunking or GPU count.
+ *              the image does not depend on chunking or GPU count.  The two
+ *              lens draws of a sample (implementation.rs:649-650) are stratified
+ *              inside every complete group of 8 samples (4 x 2 cells over the lens
+ *              square, one sample per cell): same expectation as the reference's
+ *              independent draws, less noise.
  *   counters : nullable; rays are ADDED to it.
  * Host pointers; the call blocks until the pixels are in the buffers.
  * Limits (RT_E_LIMIT): image sides <= 65535, max_reflections <= 31, at most 2^28
