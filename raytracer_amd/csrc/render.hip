@@ -835,7 +835,8 @@ render_kernel(const DevSceneView S, const RenderParams P) {
             }
         }
         // ================= rounds =====================================================================
-        // A block = the 64 pixels of one 8x8 tile x the samples of one unit.  The wave traces it in rounds
+        // A block = 8 rounds: 8 pixels x 8 units with 64 or more samples per pixel, else the 64 pixels of one 8x8
+        // tile x the samples of one unit (or fewer pixels x more units).  The wave traces it in rounds
         // of 64 rays and every lane waits for the round to end, so the rays traced side by side are of one
         // kind (camera rays with camera rays, shadow rays with shadow rays), which keeps the lanes in step
         // through the tree (measured against free-running lanes: weekend +5 %, mesh_demo +41 %).
@@ -847,6 +848,12 @@ render_kernel(const DevSceneView S, const RenderParams P) {
         // against one sample of 64 pixels per round: Dreadnaught +32 %, instanced meshes +76 %).
         // The clamped samples of a unit are added in sample order, ((0 + c0) + c1) + ..., by handing them to
         // the unit's first lane one after the other (cast_rays_into_scene's col = col + sample, :656).
+        // Tiles out of focus (blk_lens, set per tile by classify_kernel from the circle of confusion) run the
+        // other round shape: round r = the r-th sample of 8 units for the 4x2 pixels of the block, lane = unit * 8
+        // + pixel.  With the stratified lens sampler all 64 rays of such a round leave the lens from cell r, so
+        // they stay together where the 64 lens points of one pixel would spread over the circle of confusion
+        // (weekend +9 %, mesh_demo +18 %).  A lane then owns one pixel of one unit and adds its samples into
+        // the output slot round by round: the same additions in the same order.
         if (__ballot(tracing || state != NEED_SAMPLE) == 0ull) {        // wave-uniform: every lane has finished its sample
             // lane = (unit of the group, sample of the unit, pixel of the round); all sizes are powers of two
             const uint32_t l_shift = P.unit_len == 1u ? 0u : RT_SEGMENT_SHIFT, k_shift = P.round_units_shift;
