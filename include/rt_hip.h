@@ -242,8 +242,9 @@ void     rt_scene_destroy(RtScene* scene);
  *              the key of a counter-based RNG addressed (seed,x,y,sample,node):
  *              the image does not depend on chunking or GPU count.  The two
  *              lens draws of a sample (implementation.rs:649-650) are stratified
- *              inside every complete group of 8 samples (4 x 2 cells over the lens
- *              square, one sample per cell): same expectation as the reference's
+ *              inside every complete group of 16 samples (4 x 4 cells over the lens
+ *              square, one sample per cell; 4 x 2 cells for a complete group of 8
+ *              after the last of them): same expectation as the reference's
  *              independent draws, less noise.
  *   counters : nullable; rays are ADDED to it.
  * Host pointers; the call blocks until the pixels are in the buffers.

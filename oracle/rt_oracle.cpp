@@ -932,10 +932,15 @@ V3 cast_one_sample(TraceCtx& cx, const RtSettings& st, uint32_t x, uint32_t y, R
         rng.set_ctx(0, PURPOSE_LENS);
         float r0 = rng.next_f32(), r1 = rng.next_f32();
         // The product's sampler (counter mode only; the reference draws the two numbers independently):
-        // inside every complete segment of 8 samples the lens samples are stratified, sample s in cell
-        // s mod 8 of a 4 x 2 grid over the lens square, jittered inside the cell.  Same expectation, less noise.
-        if (rng.mode == ORC_RNG_COUNTER && (rng.sample / 8u + 1u) * 8u <= st.samples_per_pixel) {
-            const uint32_t cell = rng.sample & 7u;
+        // the lens samples are stratified, sample s in cell s mod 16 of a 4 x 4 grid over the lens square inside
+        // complete groups of 16 samples (s mod 8 of 4 x 2 cells in a complete segment of 8 after them),
+        // jittered inside the cell.  Same expectation, less noise.
+        if (rng.mode == ORC_RNG_COUNTER && (rng.sample / 16u + 1u) * 16u <= st.samples_per_pixel) {
+            const uint32_t cell = rng.sample & 15u;          // complete group of 16 samples: 4 x 4 cells
+            r0 = ((float)(cell & 3u) + r0) * 0.25f;
+            r1 = ((float)(cell >> 2) + r1) * 0.25f;
+        } else if (rng.mode == ORC_RNG_COUNTER && (rng.sample / 8u + 1u) * 8u <= st.samples_per_pixel) {
+            const uint32_t cell = rng.sample & 7u;           // complete segment of 8 after them: 4 x 2 cells
             r0 = ((float)(cell & 3u) + r0) * 0.25f;
             r1 = ((float)(cell >> 2) + r1) * 0.5f;
         }

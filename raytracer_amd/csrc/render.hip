@@ -689,7 +689,14 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                         // (strips are whole rows of tiles, so the 8 rows of a tile are consecutive image rows)
                         blk_py0 = P.strip_h ? P.strip_first_row + (y0 / P.strip_h) * P.strip_period_rows + (y0 % P.strip_h) : P.top + y0;
                     }
-                    blk_unit = unit_local;
+                    {
+                        // the units of the block: 8 (2^k) consecutive ones, or - lens-cell rounds over whole groups of 16
+                        // units - every second one of 16, so that the 8 samples of a round share one of the 16 lens cells of
+                        // their 16-sample groups.  blk_unit = first unit; blk_lens = round shape | unit stride shift << 1 | pixel group << 2
+                        const uint32_t k = P.round_units_shift, pairs = (blk_lens && (P.unit_count & 15u) == 0u) ? 1u : 0u;
+                        blk_lens |= (pairs << 1) | ((unit_local & ((1u << k) - 1u)) << 2);
+                        blk_unit = ((unit_local >> (k + pairs)) << (k + pairs)) + (pairs & (unit_local >> 3));
+                    }
                     round_next = 0u; s = RT_NONE;         // the block's rays are dealt to the lanes round by round, below
                     state = NEED_SAMPLE;
                 }
@@ -857,11 +864,11 @@ render_kernel(const DevSceneView S, const RenderParams P) {
         if (__ballot(tracing || state != NEED_SAMPLE) == 0ull) {        // wave-uniform: every lane has finished its sample
             // lane = (unit of the group, sample of the unit, pixel of the round); all sizes are powers of two
             const uint32_t l_shift = P.unit_len == 1u ? 0u : RT_SEGMENT_SHIFT, k_shift = P.round_units_shift;
-            const bool lens = blk_lens != 0u;
+            const bool lens = (blk_lens & 1u) != 0u;
             const uint32_t g_shift = lens ? 3u : 6u - l_shift - k_shift;                    // log2(pixels per round)
             const uint32_t q = lane & ((1u << g_shift) - 1u), j = lane >> g_shift;
             const uint32_t u_in = lens ? j : j >> l_shift, jj = lens ? 0u : j & (P.unit_len - 1u);
-            const uint32_t sub = blk_unit & ((1u << k_shift) - 1u), unit_local = ((blk_unit >> k_shift) << k_shift) + u_in;
+            const uint32_t sub = blk_lens >> 2, unit_local = blk_unit + (u_in << ((blk_lens >> 1) & 1u));
             const uint32_t x0 = blk_xy0 & 0xffffu, y0 = blk_xy0 >> 16;
             const uint32_t s_mine = (P.unit_first + unit_local) * P.unit_len + jj;
             const bool s_ok = s_mine >= P.sample_first && s_mine < P.sample_first + P.sample_count;
@@ -909,11 +916,14 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                     float lx = 0.0f, ly = 0.0f;
                     if (P.spp > 1) {                                                  // :648-653
                         float r0, r1; rng_pair(P.seed, pxy, s, 0u, PURPOSE_LENS, r0, r1);
-                        // Lens samples are stratified inside every complete segment: sample s in cell s mod 8 of a
-                        // 4 x 2 grid over the lens square, jittered inside the cell (the reference draws them
+                        // Lens samples are stratified: sample s in cell s mod 16 of a 4 x 4 grid over the lens square
+                        // (complete groups of 16 samples; 4 x 2 cells for a complete segment of 8 after them), jittered inside the cell (the reference draws them
                         // independently: same expectation, less noise - and the rays of one sample index of
                         // neighbouring pixels leave the lens close together, see the round shapes above).
-                        if (((s >> RT_SEGMENT_SHIFT) + 1u) * RT_SAMPLE_SEGMENT <= P.spp) {
+                        if (((s >> 4) + 1u) * 16u <= P.spp) {                              // a complete group of 16 samples: 4 x 4 cells
+                            const uint32_t cell = s & 15u;
+                            r0 = ((float)(cell & 3u) + r0) * 0.25f; r1 = ((float)(cell >> 2) + r1) * 0.25f;
+                        } else if (((s >> RT_SEGMENT_SHIFT) + 1u) * RT_SAMPLE_SEGMENT <= P.spp) {   // a complete segment of 8 after them: 4 x 2 cells
                             const uint32_t cell = s & 7u;
                             r0 = ((float)(cell & 3u) + r0) * 0.25f; r1 = ((float)(cell >> 2) + r1) * 0.5f;
                         }
@@ -1435,12 +1445,13 @@ int enqueue_accumulate(RtScene* scene, Workspace& ws, const RtSettings* st, cons
     bool fine = coarse_blocks < (uint64_t)scene->grid_blocks * (RT_BLOCK / 64) && scene->host_calls_in_flight.load() <= 1;
     if (const char* e = getenv("RT_FINE_SPLIT")) fine = atoi(e) != 0;                    // experiments / tests: force either split
     const uint32_t unit_len = fine ? 1u : RT_SAMPLE_SEGMENT;
-    // segments per launch: keep the scratch below ~1 GiB
+    // segments per launch: keep the scratch below ~2 GiB (a 4K frame then still runs 16 units per launch)
     const uint32_t units_per_seg = RT_SAMPLE_SEGMENT / unit_len;
-    uint32_t batch = (uint32_t)((1ull << 30) / ((uint64_t)pix_slots * 12ull * units_per_seg));
+    uint32_t batch = (uint32_t)((1ull << 31) / ((uint64_t)pix_slots * 12ull * units_per_seg));
     if (batch == 0) batch = 1;
     if (batch > nseg) batch = nseg;
-    if (batch > 8) batch &= ~7u;              // (whole groups of units that share their rounds, see round_units_shift)
+    if (batch >= 16) batch &= ~15u;           // (whole groups of units that share their rounds, see round_units_shift
+    else if (batch > 8) batch = 8;            //  and the lens-cell rounds over groups of 16 units)
     int rc = ws.partial.ensure((size_t)batch * units_per_seg * pix_slots * 12);
     if (rc) return rc;
 

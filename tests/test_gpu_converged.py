@@ -4,10 +4,13 @@ The reference path here is the oracle in its REFERENCE RNG mode: one XorShift st
 12345 (src/render.rs:142), 4 x 4 chunks on 16 threads.  The GPU uses its counter-based RNG, so the two images
 are independent Monte-Carlo estimates of the same per-pixel means.  Stated bound:
 
-  * RMSE(gpu, reference) <= 1.25 x RMSE(gpu seed A, gpu seed B) + 1e-4   (no error beyond sampling noise),
+  * RMSE(gpu, reference) <= 1.25 x sqrt((n_gpu^2 + n_ref^2) / 2) + 1e-4, n_x = RMSE between two seeds of x
+    (no error beyond the sampling noise of the two estimates; the GPU's lens samples are stratified, so its own
+    noise is the smaller of the two and is asserted to be no larger than the reference's),
   * PSNR >= 40 dB at the sample counts below (peak 1.0), and
   * |mean(gpu - reference)| <= 5e-4 (no bias).
-Measured: weekend 512 spp 46.5 dB, Mesh 256 spp 48.3 dB, Simple 256 spp 41.7 dB; bias 2e-5 .. 9e-5.
+Measured: weekend 512 spp 48.3 dB, Mesh 256 spp 50.0 dB, Simple 256 spp 42.3 dB; bias 2e-5 .. 8e-5;
+seed-to-seed noise gpu / reference sampler: 0.0027 / 0.0047, 0.0020 / 0.0038, 0.0070 / 0.0082.
 """
 import numpy as np
 import pytest
@@ -28,9 +31,12 @@ def test_converged_image_matches_the_reference_render(name, w, h, spp):
     ref, _, _, _ = oracle.render_image_mt(st, (4, 4), 16, rng_mode=ORC_RNG_XORSHIFT_CHUNK, seed=12345)
     d = gpu.astype(np.float64) - ref
     rmse = float(np.sqrt((d ** 2).mean()))
+    ref_b, _, _, _ = oracle.render_image_mt(st, (4, 4), 16, rng_mode=ORC_RNG_XORSHIFT_CHUNK, seed=999)
     noise = float(np.sqrt(((gpu.astype(np.float64) - gpu_b) ** 2).mean()))
+    noise_ref = float(np.sqrt(((ref.astype(np.float64) - ref_b) ** 2).mean()))
     psnr = 20.0 * np.log10(1.0 / rmse)
-    print(f"{name}: RMSE {rmse:.5f} (sampling noise {noise:.5f}), PSNR {psnr:.1f} dB, bias {d.mean():+.2e}")
-    assert rmse <= 1.25 * noise + 1e-4
+    print(f"{name}: RMSE {rmse:.5f} (sampling noise gpu {noise:.5f}, reference {noise_ref:.5f}), PSNR {psnr:.1f} dB, bias {d.mean():+.2e}")
+    assert rmse <= 1.25 * np.sqrt((noise ** 2 + noise_ref ** 2) / 2.0) + 1e-4
+    assert noise <= 1.05 * noise_ref
     assert psnr >= 40.0
     assert abs(d.mean()) <= 5e-4
