@@ -100,6 +100,7 @@ struct DevSceneView {
                                   // TLAS boxes are tested against the ray's whole interval like the reference does
     uint32_t sphere_entities, plane_entities;   // some entity is a sphere / a plane
     uint32_t general_xforms;      // some entity has other transforms than exactly one translation
+    float coc_rel_max;            // upper bound of a primary hit's circle of confusion, as a fraction of the image width (inf: unbounded)
     uint32_t rich_shading;        // some light is a lamp (cone), or some texture is not a plain colour / a checker
     uint32_t lds_nodes;           // the first lds_nodes node records are kept in LDS by the render kernel
     const DevNode* nodes;         // the top levels of the TLAS and of every BLAS first (breadth first), then the rest of each tree (depth first)

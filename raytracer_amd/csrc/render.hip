@@ -593,8 +593,10 @@ enum { PH_NODE = 0, PH_TRI, PH_ENTITY, PH_SHADE, PH_SHADE_PATH_HIT, PH_SHADE_SHA
 //   with everything else enabled);
 // MESH / SPHERES / PLANES: kinds of hitable among the entities (MESH: the BLAS walk and its state);
 // XFORMS: entities with other transforms than exactly one translation (S.general_xforms);
-// RICH: lamp lights, or textures other than colours and checkers (S.rich_shading).
-template <bool LOOSE, bool MESH, bool SPHERES, bool PLANES, bool XFORMS, bool RICH>
+// RICH: lamp lights, or textures other than colours and checkers (S.rich_shading);
+// DOF: some primary hit can be out of focus by more than the threshold of the lens-cell rounds (S.coc_rel_max x image
+//   width, decided per launch): without it the second round shape is compiled out (Dreadnaught +3 %).
+template <bool LOOSE, bool MESH, bool SPHERES, bool PLANES, bool XFORMS, bool RICH, bool DOF>
 __global__ void __launch_bounds__(RT_BLOCK, RT_WAVES_PER_SIMD)
 render_kernel(const DevSceneView S, const RenderParams P) {
     extern __shared__ uint32_t lds_stack[];
@@ -681,7 +683,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                     if (blk < heavy_blocks) { tile_rank = blk / P.unit_count; unit_local = blk % P.unit_count; }
                     else { const uint32_t b = blk - heavy_blocks, rest = n_tiles - heavy; unit_local = b / rest; tile_rank = heavy + b % rest; }
                     blk_tile = P.tile_order ? P.tile_order[tile_rank] : tile_rank;      // bit 31: the tile's rounds go by lens cell
-                    blk_lens = P.lens_rounds ? blk_tile >> 31 : 0u;
+                    blk_lens = (DOF && P.lens_rounds) ? blk_tile >> 31 : 0u;
                     blk_tile &= 0x7fffffffu;
                     {
                         const uint32_t x0 = (blk_tile % P.tiles_x) * 8u, y0 = (blk_tile / P.tiles_x) * 8u;
@@ -693,7 +695,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                         // the units of the block: 8 (2^k) consecutive ones, or - lens-cell rounds over whole groups of 16
                         // units - every second one of 16, so that the 8 samples of a round share one of the 16 lens cells of
                         // their 16-sample groups.  blk_unit = first unit; blk_lens = round shape | unit stride shift << 1 | pixel group << 2
-                        const uint32_t k = P.round_units_shift, pairs = (blk_lens && (P.unit_count & 15u) == 0u) ? 1u : 0u;
+                        const uint32_t k = P.round_units_shift, pairs = (DOF && blk_lens && (P.unit_count & 15u) == 0u) ? 1u : 0u;
                         blk_lens |= (pairs << 1) | ((unit_local & ((1u << k) - 1u)) << 2);
                         blk_unit = ((unit_local >> (k + pairs)) << (k + pairs)) + (pairs & (unit_local >> 3));
                     }
@@ -864,7 +866,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
         if (__ballot(tracing || state != NEED_SAMPLE) == 0ull) {        // wave-uniform: every lane has finished its sample
             // lane = (unit of the group, sample of the unit, pixel of the round); all sizes are powers of two
             const uint32_t l_shift = P.unit_len == 1u ? 0u : RT_SEGMENT_SHIFT, k_shift = P.round_units_shift;
-            const bool lens = (blk_lens & 1u) != 0u;
+            const bool lens = DOF && (blk_lens & 1u) != 0u;
             const uint32_t g_shift = lens ? 3u : 6u - l_shift - k_shift;                    // log2(pixels per round)
             const uint32_t q = lane & ((1u << g_shift) - 1u), j = lane >> g_shift;
             const uint32_t u_in = lens ? j : j >> l_shift, jj = lens ? 0u : j & (P.unit_len - 1u);
@@ -1513,19 +1515,22 @@ int enqueue_accumulate(RtScene* scene, Workspace& ws, const RtSettings* st, cons
         {
             // one instantiation per combination of scene traits (code and per-lane state a scene does not need are compiled out)
             using Kernel = void (*)(const DevSceneView, const RenderParams);
-            // index bits: 1 mesh instances, 2 spheres, 4 planes, 8 general transforms, 16 rich shading
-#define RT_K(M, S_, P_, X, R) render_kernel<false, M, S_, P_, X, R>
-#define RT_K8(X, R) nullptr, RT_K(true, false, false, X, R), RT_K(false, true, false, X, R), RT_K(true, true, false, X, R), \
-                    RT_K(false, false, true, X, R), RT_K(true, false, true, X, R), RT_K(false, true, true, X, R), RT_K(true, true, true, X, R)
-            static const Kernel kernels[32] = {RT_K8(false, false), RT_K8(true, false), RT_K8(false, true), RT_K8(true, true)};
+            // index bits: 1 mesh instances, 2 spheres, 4 planes, 8 general transforms, 16 rich shading, 32 depth of field
+#define RT_K(M, S_, P_, X, R, D) render_kernel<false, M, S_, P_, X, R, D>
+#define RT_K8(X, R, D) nullptr, RT_K(true, false, false, X, R, D), RT_K(false, true, false, X, R, D), RT_K(true, true, false, X, R, D), \
+                       RT_K(false, false, true, X, R, D), RT_K(true, false, true, X, R, D), RT_K(false, true, true, X, R, D), RT_K(true, true, true, X, R, D)
+            static const Kernel kernels[64] = {RT_K8(false, false, false), RT_K8(true, false, false), RT_K8(false, true, false), RT_K8(true, true, false),
+                                               RT_K8(false, false, true),  RT_K8(true, false, true),  RT_K8(false, true, true),  RT_K8(true, true, true)};
 #undef RT_K8
 #undef RT_K
             const DevSceneView& v = scene->view;
-            int which = (v.mesh_entities ? 1 : 0) | (v.sphere_entities ? 2 : 0) | (v.plane_entities ? 4 : 0) | (v.general_xforms ? 8 : 0) | (v.rich_shading ? 16 : 0);
+            const bool dof = v.coc_rel_max * (float)st->width > P.lens_coc_px;       // (inf x width = inf: unbounded scenes keep both round shapes)
+            int which = (v.mesh_entities ? 1 : 0) | (v.sphere_entities ? 2 : 0) | (v.plane_entities ? 4 : 0) | (v.general_xforms ? 8 : 0) | (v.rich_shading ? 16 : 0) |
+                        (dof ? 32 : 0);
             if ((which & 7) == 0) which |= 2;                                        // (an empty scene: any instantiation will do)
             static const bool show_traits = getenv("RT_DEBUG_TRAITS") != nullptr;      // diagnostics: which instantiation a scene runs
             if (show_traits) fprintf(stderr, "traits: which=%d loose=%u any_hit=%u lds_nodes=%u\n", which, v.loose_boxes, v.shadow_any_hit, v.lds_nodes);
-            const Kernel kernel = v.loose_boxes ? render_kernel<true, true, true, true, true, true> : kernels[which];
+            const Kernel kernel = v.loose_boxes ? render_kernel<true, true, true, true, true, true, true> : kernels[which];
             hipLaunchKernelGGL(kernel, dim3((uint32_t)blocks), dim3(RT_BLOCK), scene->lds_bytes, stream, scene->view, P);
         }
         HIP_TRY(hipGetLastError());
@@ -1598,7 +1603,7 @@ RtScene* rt_scene_create(const RtSceneDesc* desc, int device) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { set_error(RT_E_HIP, "hipGetDeviceProperties failed"); return fail(); }
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_kernel<true, true, true, true, true, true>, RT_BLOCK, s->lds_bytes) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_kernel<true, true, true, true, true, true, true>, RT_BLOCK, s->lds_bytes) != hipSuccess || per_cu < 1) per_cu = 1;
     s->grid_blocks = prop.multiProcessorCount * per_cu;
     if (s->shared.init(false)) return fail();
     return s;

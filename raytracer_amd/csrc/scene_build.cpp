@@ -700,6 +700,31 @@ int build_flat_scene(const RtSceneDesc* d, FlatScene& out, std::string& err) {
     v.shadow_any_hit = 1;
     for (uint64_t i = 0; i < n_mat; i++) if (d->materials[i].kind == RT_MAT_DIELECTRIC) v.shadow_any_hit = 0;
     v.mesh_entities = d->mesh_object_count ? 1u : 0u;
+    // Circle of confusion of any primary hit, bounded from the TLAS root box: camera rays meet the focal plane at
+    // t = 1 and t is the depth along the view axis over the focus distance, rays of one pixel are 2 R |1 - t| apart at t
+    // and the image is t |horizontal| wide there.  Decides whether a launch needs the lens-cell round shape at all.
+    v.coc_rel_max = INFINITY;
+    if (!(d->camera.lens_radius > 0.0f)) v.coc_rel_max = 0.0f;
+    else if (n_ent > 0 && !box_is_infinite(tlas.nodes[0].box)) {
+        const RtCamera& c = d->camera;
+        const double ctr[3] = {c.lower_left_corner.x + 0.5 * c.horizontal.x + 0.5 * c.vertical.x - c.origin.x,
+                               c.lower_left_corner.y + 0.5 * c.horizontal.y + 0.5 * c.vertical.y - c.origin.y,
+                               c.lower_left_corner.z + 0.5 * c.horizontal.z + 0.5 * c.vertical.z - c.origin.z};
+        const double f = std::sqrt(ctr[0] * ctr[0] + ctr[1] * ctr[1] + ctr[2] * ctr[2]);
+        const double hlen = std::sqrt((double)c.horizontal.x * c.horizontal.x + (double)c.horizontal.y * c.horizontal.y + (double)c.horizontal.z * c.horizontal.z);
+        const Box& rb = tlas.nodes[0].box;
+        double zmin = 1e300, zmax = -1e300;
+        for (int k = 0; k < 8; k++) {
+            const double px = (k & 1) ? rb.hi.x : rb.lo.x, py = (k & 2) ? rb.hi.y : rb.lo.y, pz = (k & 4) ? rb.hi.z : rb.lo.z;
+            const double z = ((px - c.origin.x) * ctr[0] + (py - c.origin.y) * ctr[1] + (pz - c.origin.z) * ctr[2]) / f;
+            zmin = std::min(zmin, z); zmax = std::max(zmax, z);
+        }
+        if (f > 0.0 && hlen > 0.0 && zmin > 1e-6 * f && std::isfinite(zmax)) {
+            const double t_lo = zmin / f, t_hi = zmax / f;
+            const double worst = std::max(std::fabs(1.0 - t_lo) / t_lo, std::fabs(1.0 - t_hi) / t_hi);
+            v.coc_rel_max = (float)(1.05 * 2.0 * c.lens_radius * worst / hlen);
+        }
+    }
     v.rich_shading = 0;
     for (uint64_t i = 0; i < d->light_count; i++) if (d->lights[i].kind == RT_LIGHT_LAMP) v.rich_shading = 1;
     for (uint64_t i = 0; i < n_tex; i++) if (d->textures[i].kind != RT_TEX_COLOR && d->textures[i].kind != RT_TEX_CHECKER) v.rich_shading = 1;
