@@ -23,6 +23,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -605,6 +606,13 @@ inline bool slab_entry(const AABB& b, const Ray& ray, float t_min, float t_max, 
 // Near-child-first traversal; `nodes` counts box tests (root 1, then 2 per
 // inner node visited). A popped node whose entry lies beyond the current best
 // hit is skipped without a new box test.
+// `best_t` is the CULLING bound, not the best hit's t: the boxes of the reference do not bound the
+// computed t of their hits to the last bit (an axis-aligned triangle lies in a face of its own box, and
+// its plane-equation t is often 1-3 ulp before the box's slab entry; rotated entities add the rounding of
+// the rotated ray), so a walk that culls at exactly the best t loses candidates the reference finds -
+// 450 of 4.4 M sample rays on the 900-instance scene, nearly all exact ties between coincident faces.
+// The caller therefore keeps best_t = t_best * ORC_CULL_SLACK (the product's RT_CULL_SLACK).
+const float ORC_CULL_SLACK = 1.0009765625f;    // 1 + 2^-10
 template <class Leaf>
 void ordered_traverse(const Bvh& bvh, const Ray& ray, float t_min, const float& best_t, uint64_t& nodes, Leaf leaf) {
     struct Item { size_t node; float entry; };
@@ -630,6 +638,7 @@ void ordered_traverse(const Bvh& bvh, const Ray& ray, float t_min, const float& 
     }
 }
 
+float g_cull_slack = ORC_CULL_SLACK;      // (diagnostics can set it: orc_set_cull_slack)
 MinHit hit_closest_min(const OrcScene& s, const RankTables& rk, const Ray& ray, float t_min, float t_max, Counters& cn) {
     MinHit best; float best_t = t_max; uint32_t best_erank = 0, best_trank = 0;
     ordered_traverse(s.tlas, ray, t_min, best_t, cn.min_nodes, [&](size_t ei) {
@@ -644,7 +653,7 @@ MinHit hit_closest_min(const OrcScene& s, const RankTables& rk, const Ray& ray, 
         auto consider = [&](float t, int32_t tri, uint32_t trank) {
             uint32_t er = rk.tlas_rank[ei];
             bool better = !best.have || t < best.t || (t == best.t && (er < best_erank || (er == best_erank && trank < best_trank)));
-            if (better) { best.have = true; best.t = t; best.entity = (int32_t)ei; best.tri = tri; best_erank = er; best_trank = trank; best_t = t; }
+            if (better) { best.have = true; best.t = t; best.entity = (int32_t)ei; best.tri = tri; best_erank = er; best_trank = trank; best_t = fminf(t * g_cull_slack, t_max); }
         };
         HitRecord h;
         switch (e.desc.hitable_kind) {
@@ -670,11 +679,71 @@ struct TraceCtx {
     const RankTables* ranks;   // non-null => stats mode
 };
 
+// --- diagnostics of a disagreement (stats mode only; not reference code): where do the boxes of the
+// two winners lie along the ray?  A hit whose t is outside the [entry, exit] of a box that is supposed
+// to bound it is what a t_max-shrinking walk can lose.
+std::mutex g_mismatch_lock;
+std::vector<OrcMismatch> g_mismatches;
+uint32_t g_mismatch_cap = 0;
+
+inline void slab_span(const AABB& b, const Ray& ray, float& entry, float& exit_) {
+    // hit_aabb's arithmetic (implementation.rs:102-115) over (-inf, +inf), never rejecting
+    const float o[3] = {ray.origin.x, ray.origin.y, ray.origin.z};
+    const float d[3] = {ray.direction.x, ray.direction.y, ray.direction.z};
+    const float mn[3] = {b.min.x, b.min.y, b.min.z};
+    const float mx[3] = {b.max.x, b.max.y, b.max.z};
+    float t_min = -F_INF, t_max = F_INF;
+    for (int k = 0; k <= 2; k++) {
+        float inv_d = 1.0f / d[k];
+        float t0 = (mn[k] - o[k]) * inv_d, t1 = (mx[k] - o[k]) * inv_d;
+        if (inv_d < 0.0f) { float tmp = t0; t0 = t1; t1 = tmp; }
+        t_min = t0 > t_min ? t0 : t_min;
+        t_max = t1 < t_max ? t1 : t_max;
+    }
+    entry = t_min; exit_ = t_max;
+}
+
+void describe_winner(const OrcScene& s, const Ray& ray, int32_t ent, int32_t tri, float* spans /* 6 */) {
+    for (int k = 0; k < 6; k++) spans[k] = 0.0f;
+    if (ent < 0) return;
+    const Entity& e = s.entities[(size_t)ent];
+    BvhBounds eb = entity_bounds(s, e);
+    slab_span(eb.aabb, ray, spans[0], spans[1]);
+    if (e.desc.hitable_kind != RT_HITABLE_MESH || tri < 0) return;
+    Ray r = ray;
+    for (const V3& t : e.translations) r.origin = r.origin - t;
+    for (const RtRotation& rot : e.rotations) {
+        r.origin = rotate_about_axis(r.origin, from(rot.axis), -rot.theta);
+        r.direction = rotate_about_axis(r.direction, from(rot.axis), -rot.theta);
+    }
+    const MeshBvhRoot& m = s.meshes[s.mesh_objects[e.desc.hitable_index].mesh_index];
+    slab_span(m.bvh.nodes[0].aabb, r, spans[2], spans[3]);
+    slab_span(tri_bounds(m.tris[(size_t)tri]).aabb, r, spans[4], spans[5]);
+}
+
+void record_mismatch(const OrcScene& s, const Ray& ray, float t_min, float t_max, bool have, const HitRecord& best, const MinHit& m) {
+    std::lock_guard<std::mutex> g(g_mismatch_lock);
+    if (g_mismatches.size() >= g_mismatch_cap) return;
+    OrcMismatch r{};
+    r.o[0] = ray.origin.x; r.o[1] = ray.origin.y; r.o[2] = ray.origin.z;
+    r.d[0] = ray.direction.x; r.d[1] = ray.direction.y; r.d[2] = ray.direction.z;
+    r.t_min = t_min; r.t_max = t_max;
+    r.ref_have = have ? 1 : 0; r.min_have = m.have ? 1 : 0;
+    r.ref_t = have ? best.t : 0.0f; r.ref_ent = have ? best.entity_index : -1; r.ref_tri = have ? best.tri_index : -1;
+    r.min_t = m.have ? m.t : 0.0f; r.min_ent = m.have ? m.entity : -1; r.min_tri = m.have ? m.tri : -1;
+    describe_winner(s, ray, r.ref_ent, r.ref_tri, r.ref_spans);
+    describe_winner(s, ray, r.min_ent, r.min_tri, r.min_spans);
+    g_mismatches.push_back(r);
+}
+
 bool hit_closest(TraceCtx& cx, const Ray& ray, float t_min, float t_max, HitRecord& best) {
     bool have = hit_closest_ref(cx.s, ray, t_min, t_max, best, cx.cn);
     if (cx.ranks) {
         MinHit m = hit_closest_min(cx.s, *cx.ranks, ray, t_min, t_max, cx.cn);
-        if (m.have != have || (have && (m.t != best.t || m.entity != best.entity_index || m.tri != best.tri_index))) cx.cn.min_mismatch++;
+        if (m.have != have || (have && (m.t != best.t || m.entity != best.entity_index || m.tri != best.tri_index))) {
+            cx.cn.min_mismatch++;
+            if (g_mismatch_cap) record_mismatch(cx.s, ray, t_min, t_max, have, best, m);
+        }
     }
     return have;
 }
@@ -1197,6 +1266,20 @@ int orc_primary_hits(const OrcScene* s, const RtSettings* st, const RtRenderChun
             }
     } catch (StackOverflow&) { return fail(RT_E_DEPTH, "BVH traversal stack overflow"); }
     return RT_OK;
+}
+
+void orc_set_cull_slack(float factor) { g_cull_slack = factor >= 1.0f ? factor : ORC_CULL_SLACK; }
+
+void orc_mismatch_capture(uint32_t capacity) {
+    std::lock_guard<std::mutex> g(g_mismatch_lock);
+    g_mismatch_cap = capacity; g_mismatches.clear();
+}
+
+uint32_t orc_mismatch_read(OrcMismatch* out, uint32_t capacity) {
+    std::lock_guard<std::mutex> g(g_mismatch_lock);
+    uint32_t n = 0;
+    for (; n < g_mismatches.size() && n < capacity; n++) out[n] = g_mismatches[n];
+    return n;
 }
 
 int64_t orc_scene_bvh_order(const OrcScene* s, int64_t mesh_index, uint32_t* out, uint64_t capacity) {

@@ -95,6 +95,23 @@ int orc_primary_hits(const OrcScene* s, const RtSettings* settings,
                      float* t_out, float* normal_out,
                      int32_t* entity_out, int32_t* tri_out);
 
+/* Diagnostics of OrcCounters.min_mismatch (stats mode): the rays on which the ordered, shrinking
+ * traversal disagreed with the reference-order one.  `*_spans` = [entry, exit] along the ray, by
+ * hit_aabb's arithmetic over the whole line, of three boxes of that winner: its entity box (world
+ * space), its mesh's root box and its triangle's own box (entity space; 0 for non-mesh winners). */
+typedef struct OrcMismatch {
+    float o[3], d[3], t_min, t_max;
+    int32_t ref_have, min_have;
+    float ref_t, min_t;
+    int32_t ref_ent, ref_tri, min_ent, min_tri;
+    float ref_spans[6], min_spans[6];
+} OrcMismatch;
+/* start capturing up to `capacity` records (process-wide; 0 stops and clears) / copy them out */
+/* factor (>= 1) by which the shrinking walk of stats mode widens its culling bound; default 1 + 2^-10 */
+void     orc_set_cull_slack(float factor);
+void     orc_mismatch_capture(uint32_t capacity);
+uint32_t orc_mismatch_read(OrcMismatch* out, uint32_t capacity);
+
 /* Candidate order of bvh.rs:210-236 when every box is hit (leaf enumeration).
  * mesh_index<0: TLAS. Returns count. */
 int64_t orc_scene_bvh_order(const OrcScene* s, int64_t mesh_index,

@@ -105,6 +105,18 @@ __device__ __forceinline__ Word4 ldw(const Word4* p) {
 #define RT_BIAS 0.004f                       /* implementation.rs:498 */
 #define RT_F32_MAX 3.40282347e+38f
 #define RT_NONE 0xFFFFFFFFu
+// Boxes are culled against best_t = (t of the best hit so far) x RT_CULL_SLACK, not against that t itself.
+// The reference tests every box against the ray's whole interval and takes the minimum afterwards
+// (bvh.rs:210-236), and its boxes do not bound the COMPUTED t of their hits to the last bit: an axis-aligned
+// triangle lies in a face of its own leaf box and its plane-equation t (plane.rs:12-13) comes out 1-3 ulp
+// before the slab entry of that face (implementation.rs:102-115); entity boxes add the rounding of the
+// rotated ray (a few hundred ulp for unit-length secondary rays far from the origin).  Culling at exactly
+// the best t then drops candidates the reference finds - on the 900-instance scene 450 of 4.4 M sample rays,
+// nearly all exact ties between coincident faces that the visit rank must decide (tools/mismatch_diag.py).
+// 2^-10 = 8000 ulp of margin costs 0.8 % more node steps there, 0.2 % elsewhere.  Winners are still chosen
+// by the exact (t, rank) order, so a candidate visited needlessly never changes the result; the bound never
+// exceeds the ray's t_max, so no box is entered that the reference's own test would reject.
+#define RT_CULL_SLACK 1.0009765625f
 
 // ===========================================================================
 // counter-based RNG: Philox4x32-10 (Random123), counter = (x | y<<16, sample,
@@ -255,7 +267,7 @@ __device__ __forceinline__ void trace(const DevSceneView& S, const F3 wo, const 
                 if (fabsf(denominator) < 1.0e-6f) continue;
                 const float t = dot(A - o, normal) / denominator;               // plane.rs:12-13
                 if (t < t_min || t > t_max) continue;                           // mesh.rs:28
-                if (t > best_t) continue;                                       // cannot win
+                if (t > best.t) continue;                                       // cannot win
                 const F3 p = o + (d * t);
                 const F3 n_abp = cross(B - A, p - A);
                 if (dot(normal, n_abp) < 0.0f) continue;
@@ -263,14 +275,14 @@ __device__ __forceinline__ void trace(const DevSceneView& S, const F3 wo, const 
                 if (dot(normal, n_bcp) < 0.0f) continue;
                 const F3 n_cap = cross(A - C, p - C);
                 if (dot(normal, n_cap) < 0.0f) continue;
-                bool better = best.ent == RT_NONE || t < best_t;
-                if (!better && t == best_t) {
+                bool better = best.ent == RT_NONE || t < best.t;
+                if (!better && t == best.t) {
                     // exact tie: the reference keeps the candidate it visits first
                     // (implementation.rs:415, mesh.rs:96-98); ranks are only fetched here
                     better = cur_erank < best.erank ||
                              (cur_erank == best.erank && best.tri != RT_NONE && S.tri_rank[ti] < S.tri_rank[best.tri]);
                 }
-                if (better) { best.t = t; best.ent = cur_ent; best.tri = ti; best.erank = cur_erank; best_t = t; }
+                if (better) { best.t = t; best.ent = cur_ent; best.tri = ti; best.erank = cur_erank; best_t = fminf(t * RT_CULL_SLACK, t_max); }
             }
             cur = pop();
             continue;
@@ -330,8 +342,8 @@ __device__ __forceinline__ void trace(const DevSceneView& S, const F3 wo, const 
             }
             if (hit) {
                 const uint32_t erank = ldw(ew + 2).u[3];
-                if (best.ent == RT_NONE || t < best_t || (t == best_t && erank < best.erank)) {
-                    best.t = t; best.ent = ei; best.tri = RT_NONE; best.erank = erank; best_t = t;
+                if (best.ent == RT_NONE || t < best.t || (t == best.t && erank < best.erank)) {
+                    best.t = t; best.ent = ei; best.tri = RT_NONE; best.erank = erank; best_t = fminf(t * RT_CULL_SLACK, t_max);
                 }
             }
         }
@@ -1024,7 +1036,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                             if (fabsf(denominator) < 1.0e-6f) continue;
                             const float t = dot(A - o, normal) / denominator;               // plane.rs:12-13
                             if (t < t_min || t > t_max) continue;                           // mesh.rs:28
-                            if (t > best_t) continue;                                       // cannot win
+                            if (t > best.t) continue;                                       // cannot win
                             const F3 p = o + (d * t);
                             const F3 n_abp = cross(B - A, p - A);
                             if (dot(normal, n_abp) < 0.0f) continue;
@@ -1032,14 +1044,14 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                             if (dot(normal, n_bcp) < 0.0f) continue;
                             const F3 n_cap = cross(A - C, p - C);
                             if (dot(normal, n_cap) < 0.0f) continue;
-                            bool better = best.ent == RT_NONE || t < best_t;
-                            if (!better && t == best_t) {
+                            bool better = best.ent == RT_NONE || t < best.t;
+                            if (!better && t == best.t) {
                                 // exact tie: the reference keeps the candidate it visits first
                                 // (implementation.rs:415, mesh.rs:96-98); ranks are only fetched here
                                 better = cur_erank < best.erank ||
                                          (cur_erank == best.erank && best.tri != RT_NONE && S.tri_rank[ti] < S.tri_rank[best.tri]);
                             }
-                            if (better) { best.t = t; best.ent = cur_ent; best.tri = ti; best.erank = cur_erank; best_t = t; }
+                            if (better) { best.t = t; best.ent = cur_ent; best.tri = ti; best.erank = cur_erank; best_t = fminf(t * RT_CULL_SLACK, t_max); }
                         }
                         cur = pop();
                     } else {
@@ -1102,8 +1114,8 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                             }
                             if (hit) {
                                 const uint32_t erank = ldw(ew + 2).u[3];
-                                if (best.ent == RT_NONE || t < best_t || (t == best_t && erank < best.erank)) {
-                                    best.t = t; best.ent = ei; best.tri = RT_NONE; best.erank = erank; best_t = t;
+                                if (best.ent == RT_NONE || t < best.t || (t == best.t && erank < best.erank)) {
+                                    best.t = t; best.ent = ei; best.tri = RT_NONE; best.erank = erank; best_t = fminf(t * RT_CULL_SLACK, t_max);
                                 }
                             }
                         }

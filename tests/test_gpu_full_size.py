@@ -1,24 +1,30 @@
-"""Parity at BASELINE.json's full sizes (configs[1] weekend 1920x1080 x 256 spp, configs[2]
-Dreadnaught 1080p x 128 spp), where the oracle cannot render the whole frame in seconds:
-size-independent properties of the whole frame + the oracle on sampled chunks of it."""
+"""Parity at BASELINE.json's full sizes, where the oracle cannot render the whole frame in seconds:
+size-independent properties of the whole frame + the oracle on sampled chunks of it.
+  weekend      configs[1]  1920x1080 x 256 spp
+  dreadnaught  configs[2]  1920x1080 x 128 spp
+  meshdemo     configs[3]  3840x2160 x 1024 spp (glass + metal meshes)
+  dootdoot     configs[4]  3840x2160, 900 x 11 101 instanced triangles; 64 spp for the whole-frame properties,
+               the full 4096 spp on a sampled chunk (test_dootdoot_chunk_at_4096_spp)"""
 import numpy as np
 import pytest
 
 from raytracer_amd import (CameraConfiguration, RenderChunk, RenderSettings, Scene, SceneBuilder, create_render_chunks,
                            resolve_device, sample_segment, strip_rows)
 from tests.oracle import ORC_RNG_COUNTER, OracleScene
-from tests.test_gpu_parity import check_image
+from tests.test_gpu_parity import PRIMARY_RTOL, check_image
 
 pytestmark = pytest.mark.gpu
 
-CONFIGS = {"weekend": ("Random Spheres", 1920, 1080, 256, 8), "dreadnaught": ("Dreadnaught", 1920, 1080, 128, 8)}
+DOOT = {"Count": 30, "Spacing": 30}
+CONFIGS = {"weekend": ("Random Spheres", 1920, 1080, 256, 8, None), "dreadnaught": ("Dreadnaught", 1920, 1080, 128, 8, None),
+           "meshdemo": ("Mesh", 3840, 2160, 1024, 8, None), "dootdoot": ("Doot Doot", 3840, 2160, 64, 8, DOOT)}
 
 
 @pytest.fixture(scope="module", params=list(CONFIGS))
 def frame(request):
     import torch
-    name, w, h, spp, depth = CONFIGS[request.param]
-    b = SceneBuilder.sample(name, CameraConfiguration(w, h, lens_radius=0.1))
+    name, w, h, spp, depth, params = CONFIGS[request.param]
+    b = SceneBuilder.sample(name, CameraConfiguration(w, h, lens_radius=0.1), params=params)
     scene = Scene(b, 0)
     st = RenderSettings(w, h, depth, spp)
     rgb = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda:0")
@@ -27,7 +33,8 @@ def frame(request):
     scene.render_chunk_device(st, RenderChunk(0, 0, w, h), 12345, rgb.data_ptr(), rgba.data_ptr(), w, 0, 0, cn.data_ptr(),
                               torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
-    return dict(b=b, scene=scene, st=st, w=w, h=h, spp=spp, rgb=rgb, rgba=rgba, counters=cn.tolist())
+    yield dict(key=request.param, b=b, scene=scene, st=st, w=w, h=h, spp=spp, rgb=rgb, rgba=rgba, counters=cn.tolist())
+    scene.close()
 
 
 def test_ray_accounting(frame):
@@ -112,3 +119,50 @@ def test_sampled_chunks_match_the_oracle_at_full_spp(frame):
         ch = RenderChunk(l, t, 24, 24)
         ref, _, _ = oracle.render_chunk(s["st"], ch, ORC_RNG_COUNTER, 12345, sum_segment=sample_segment())
         check_image(host[t:t + 24, l:l + 24], ref, outlier_frac=5e-3)
+
+
+def test_sampled_primary_hits_match_the_oracle(frame):
+    """Parity gate 1 at the full frame size: t, normal, entity and triangle ids of 64x64 chunks sampled from the frame."""
+    s = frame
+    oracle = OracleScene(s["b"])
+    rng = np.random.default_rng(11)
+    st1 = RenderSettings(s["w"], s["h"], 8, 1)
+    exact = []
+    for _ in range(12):
+        l, t = int(rng.integers(0, s["w"] - 64)), int(rng.integers(0, s["h"] - 64))
+        ch = RenderChunk(l, t, 64, 64)
+        gt, gn, ge, gtri = s["scene"].primary_hits(st1, ch)
+        rt, rn, re, rtri = oracle.primary_hits(st1, ch)
+        assert np.array_equal(ge, re) and np.array_equal(gtri, rtri), (s["key"], l, t, int((ge != re).sum()), int((gtri != rtri).sum()))
+        hit = re >= 0
+        np.testing.assert_allclose(gt[hit], rt[hit], rtol=PRIMARY_RTOL, atol=0)
+        np.testing.assert_allclose(gn[hit], rn[hit], rtol=PRIMARY_RTOL, atol=1e-6)
+        exact.append(float((gt == rt).mean()))
+    assert min(exact) == 1.0, exact          # in fact bit-identical
+
+
+def test_dootdoot_chunk_at_4096_spp():
+    """BASELINE configs[4] at its own sample count, on one chunk the oracle can afford: 512 segments of 8 samples,
+    accumulated as the 8 ranks of the spp split would (8 x 512 samples) and as one call."""
+    import torch
+    from raytracer_amd.dist import sample_range_of_rank
+    w, h, spp = 3840, 2160, 4096
+    b = SceneBuilder.sample("Doot Doot", CameraConfiguration(w, h, lens_radius=0.1), params=DOOT)
+    scene, oracle = Scene(b, 0), OracleScene(b)
+    st, ch = RenderSettings(w, h, 8, spp), RenderChunk(1912, 1076, 16, 16)
+    one, _, cn = scene.render_chunk(st, ch, seed=12345)
+    stream = torch.cuda.current_stream().cuda_stream
+    acc = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda:0")
+    for r in range(8):
+        first, count = sample_range_of_rank(spp, r, 8)
+        scene.accumulate_chunk_device(st, ch, 12345, first, count, acc.data_ptr(), None, stream)
+    out = torch.zeros((h * w, 3), dtype=torch.float32, device="cuda:0")
+    resolve_device(0, acc.data_ptr(), w * h, spp, out.data_ptr(), None, stream)
+    torch.cuda.synchronize()
+    split = out.view(h, w, 3)[ch.top:ch.top + 16, ch.left:ch.left + 16].cpu().numpy()
+    assert np.array_equal(split, one)
+    assert cn.samples == 16 * 16 * spp == cn.primary
+    ref, _, rcn = oracle.render_chunk(st, ch, ORC_RNG_COUNTER, 12345, sum_segment=sample_segment())
+    check_image(one, ref, outlier_frac=5e-3)
+    assert rcn.rays.primary == cn.primary and abs(rcn.rays.shadow - cn.shadow) <= 2e-3 * rcn.rays.shadow
+    scene.close()

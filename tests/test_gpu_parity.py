@@ -54,20 +54,50 @@ def check_image(rgb, ref, atol=IMAGE_ATOL, outlier_frac=IMAGE_OUTLIER_FRAC, mean
     return outliers, float(d.mean()), float(d.max())
 
 
-@pytest.mark.parametrize("name,w,h", [
-    ("Random Spheres", 400, 225),
-    ("Mesh", 320, 180),
-    ("Simple", 320, 180),
-    ("Mirrors", 320, 180),
-    ("Triangles", 160, 90),
-    ("Mega Cube", 160, 90),
+@pytest.mark.parametrize("name,w,h,params", [
+    ("Random Spheres", 400, 225, None),
+    ("Mesh", 320, 180, None),
+    ("Simple", 320, 180, None),
+    ("Mirrors", 320, 180, None),
+    ("Triangles", 160, 90, None),
+    ("Mega Cube", 160, 90, None),
+    ("Dreadnaught", 320, 180, None),
+    ("Fleet", 320, 180, None),                                     # 1 331 rotated instances of a 300-triangle mesh (samples.rs:631-665)
+    ("Doot Doot", 320, 180, {"Count": 6, "Spacing": 30}),          # BASELINE configs[4] geometry, 36 instances: whole frame
+    ("Doot Doot", 480, 270, {"Count": 30, "Spacing": 30}),         # ... and all 900 (scene_dootdoot.rs:57-83)
 ])
-def test_primary_hits_match_oracle(name, w, h):
-    b, scene, oracle = make(name, w, h)
+def test_primary_hits_match_oracle(name, w, h, params):
+    b, scene, oracle = make(name, w, h, params=params)
     st = RenderSettings(w, h, 8, 1)
     exact, cover = check_primary(scene, oracle, st, RenderChunk(0, 0, w, h))
     print(f"{name}: {exact * 100:.3f}% of t bit-identical, {cover * 100:.1f}% pixels hit")
     assert exact > 0.999
+
+
+def test_ties_between_coincident_faces_go_to_the_reference_winner():
+    """SKELETON.obj has coincident axis-aligned faces; the reference keeps the one it visits first (mesh.rs:96-98).  The
+    plane-equation t of such a face is often 1-3 ulp BEFORE the slab entry of its own (flat) leaf box, so a walk that
+    culls boxes at exactly the best t so far never sees the second face: the oracle's shrinking walk without slack
+    disagrees with the reference order on these chunks (55 / 43 / 30 rays; tools/mismatch_diag.py), with the product's
+    RT_CULL_SLACK it agrees, and the kernel returns the reference's winner in every pixel."""
+    import ctypes as C
+    from tests.oracle import lib
+    w, h = 1920, 1080
+    b, scene, oracle = make("Doot Doot", w, h, params={"Count": 30, "Spacing": 30})
+    L = lib()
+    L.orc_set_cull_slack.argtypes = [C.c_float]
+    st = RenderSettings(w, h, 1, 1)
+    try:
+        for left, top in ((1728, 960), (1088, 576), (832, 768)):
+            ch = RenderChunk(left, top, 64, 64)
+            L.orc_set_cull_slack(1.0)                      # no slack: the walk loses reference winners here
+            assert oracle.render_chunk(st, ch, ORC_RNG_COUNTER, 1, 0, True)[2].min_mismatch > 0
+            L.orc_set_cull_slack(0.0)                      # (< 1: back to the default, the product's factor)
+            assert oracle.render_chunk(st, ch, ORC_RNG_COUNTER, 1, 0, True)[2].min_mismatch == 0
+            exact, _ = check_primary(scene, oracle, st, ch)
+            assert exact == 1.0
+    finally:
+        L.orc_set_cull_slack(0.0)
 
 
 @pytest.mark.parametrize("name,w,h,spp,depth", [
@@ -81,6 +111,8 @@ def test_primary_hits_match_oracle(name, w, h):
     ("Entity Transforms Test", 160, 90, 2, 5),  # 1000 translated spheres over a translated + rotated plane
     ("Spaceships", 160, 90, 1, 5),              # two OBJ meshes, four instances, rotated
     ("Capsule", 120, 68, 1, 5),
+    ("Fleet", 160, 90, 2, 5),
+    ("Doot Doot", 160, 90, 2, 8),               # default Count: the instanced skeletons, four stacked rotations each
 ])
 def test_image_matches_oracle(name, w, h, spp, depth):
     b, scene, oracle = make(name, w, h)
