@@ -2,40 +2,48 @@
 """Benchmark of the hot path: Mrays/s of the render core on N MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1 is launched by torch.distributed.run, one rank per GPU over RCCL)
 
-A "step" is one full render pass of the workload frame: every sample of every
-pixel goes through camera-ray generation, two-level BVH traversal, scatter,
-shadow rays and shading (src/render.rs:148-159 over the whole image), and for
-N > 1 the composite of the tiles onto rank 0.  A ray = one Scene::hit_closest
-call (implementation.rs:372), counted by the kernel itself.
+N > 1: one rank per GPU over RCCL.  Started directly (`python bench.py --gpus 8`) this process
+launches `python -m torch.distributed.run --nproc-per-node N ... bench.py` as a child BEFORE any
+GPU call and relays rank 0's JSON line; started by torch.distributed.run (RANK / WORLD_SIZE in
+the environment) it is one of the ranks.  A world size that differs from --gpus, or more ranks
+than visible GPUs, is an error - never a silent one-GPU run.
 
-Workload at N = 1 (BASELINE.json configs[1], the configuration the metric is
-quoted on): raytracer-samples "Random Spheres" (the `weekend` scene), 1920x1080,
-256 spp, max depth 8, lens radius 0.1, seed 12345.  `--workload` selects the
-other BASELINE configs (they are parity/diagnostic cases, not the default line).
+A "step" is one full render pass of the workload frame: every sample of every pixel goes through
+camera-ray generation, two-level BVH traversal, scatter, shadow rays and shading
+(src/render.rs:148-159 over the whole image), and for N > 1 the composite onto rank 0.  A ray =
+one Scene::hit_closest call (implementation.rs:372), counted by the kernel itself.
 
-N > 1: the image is cut into 8-row strips (create_render_chunks(size,[1,n]),
-viewport.rs:30-54), dealt round-robin to the ranks; every rank renders all its
-strips in one launch into device memory and rank 0 gathers them over RCCL/xGMI
-(one exchange per frame).  The frame is fixed, so scaling is "strong".
+Workload at N = 1 (BASELINE.json configs[1], the configuration the metric is quoted on):
+raytracer-samples "Random Spheres" (the `weekend` scene), 1920x1080, 256 spp, max depth 8, lens
+radius 0.1, seed 12345.  The default run also times the north_star's TARGET scene (configs[2], the
+OBJ mesh BVH scene: Dreadnaught 1080p x 128 spp) and emits it under "target_scene" of the same JSON
+line with its own roofline / cpu_baseline / gpu_over_cpu.  `--workload` selects any other BASELINE
+config as the headline (parity / diagnostic cases, not the default line).
+
+N > 1, --mode tiles: the image is cut into 8-row strips dealt round-robin to the ranks; every rank
+renders all its strips in one launch into device memory and rank 0 gathers them over RCCL/xGMI
+(one exchange per frame).  --mode spp: every rank renders the whole frame for its range of sample
+indices into a float3 accumulator; rank 0 gathers and adds them in rank order.  The frame is fixed,
+so scaling is "strong".
 
 The JSON line also carries
-  roofline     : the render kernel against the f32 VALU peak (the path is f32
-                 vector arithmetic + latency bound; no MFMA: not a dense
-                 contraction; scenes are cache resident so HBM is reported as a
-                 second object, `roofline_hbm`).  Algorithmic flops/bytes per ray
-                 follow SURVEY.md 8(d): per-ray node / primitive / transform
-                 counts of an ordered, t_max-shrinking traversal, measured by the
-                 oracle on a sample of the same frame, times fixed per-op costs.
-  cpu_baseline : the oracle's restatement of the reference's multithreaded CPU
-                 path (kind "port"; the Rust reference cannot be built: no rustc),
-                 timed on this box's host cores on a bounded sample of the same
-                 frame.
+  roofline     : the render kernel against the f32 VALU peak (the path is f32 vector arithmetic +
+                 latency bound; no MFMA: not a dense contraction; scenes are cache resident so HBM
+                 is reported as a second object, `roofline_hbm`).  Algorithmic flops/bytes per ray
+                 follow SURVEY.md 8(d): per-ray node / primitive / transform counts of an ordered,
+                 t_max-shrinking traversal, measured by the oracle on a sample of the same frame,
+                 times fixed per-op costs.
+  cpu_baseline : the oracle's restatement of the reference's multithreaded CPU path (kind "port";
+                 the Rust reference cannot be built: no rustc), timed on this box's host cores on a
+                 bounded sample of the same frame: median of 3 runs with 16 threads (the reference
+                 UI's maximum, src/settings.rs:201) and with all the threads this process may use.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -54,54 +62,65 @@ WORKLOADS = {
     # name: (scene, width, height, spp, depth, lens_radius, params)
     "weekend-1080p-256spp": ("Random Spheres", 1920, 1080, 256, 8, 0.1, None),          # configs[1]
     "weekend-400x225-16spp": ("Random Spheres", 400, 225, 16, 8, 0.1, None),            # configs[0]
-    "dreadnaught-1080p-128spp": ("Dreadnaught", 1920, 1080, 128, 8, 0.1, None),         # configs[2]
+    "dreadnaught-1080p-128spp": ("Dreadnaught", 1920, 1080, 128, 8, 0.1, None),         # configs[2]: the target scene
     "meshdemo-4k-1024spp": ("Mesh", 3840, 2160, 1024, 8, 0.1, None),                    # configs[3]
     "dootdoot-4k-64spp": ("Doot Doot", 3840, 2160, 64, 8, 0.1, {"Count": 30, "Spacing": 30}),  # configs[4] geometry
-    "dootdoot-4k-4096spp": ("Doot Doot", 3840, 2160, 4096, 8, 0.1, {"Count": 30, "Spacing": 30}),  # configs[4] in full (~30 s per frame on one GPU)
+    "dootdoot-4k-4096spp": ("Doot Doot", 3840, 2160, 4096, 8, 0.1, {"Count": 30, "Spacing": 30}),  # configs[4] in full (~12 s per frame on one GPU)
 }
+HEADLINE = "weekend-1080p-256spp"
+TARGET_SCENE = "dreadnaught-1080p-128spp"
+SEED = 12345
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="weekend-1080p-256spp", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=HEADLINE, choices=sorted(WORKLOADS))
     ap.add_argument("--mode", default="tiles", choices=["tiles", "spp"], help="N>1: tile partition + gather, or spp split + accumulator sum")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-chunk-stride", type=int, default=0, help="oracle sample: every k-th of 32x32 chunks")
-    args = ap.parse_args()
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle legs (roofline statistics and CPU baseline)")
+    ap.add_argument("--no-target-scene", action="store_true", help="do not also time the target scene (configs[2])")
+    ap.add_argument("--launcher", action="store_true", help="go through torch.distributed.run even for --gpus 1 (rehearsal of the N > 1 path)")
+    ap.add_argument("--cpu-seconds", type=float, default=4.0, help="CPU work per baseline run (3 runs per thread count)")
+    return ap.parse_args(argv)
 
-    import numpy as np
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks as a child job (before this
+    process touches a GPU), relay its output, exit with its status."""
+    import torch                                    # device_count() does not initialise the GPU
+    visible = torch.cuda.device_count()
+    if args.gpus > visible:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but only {visible} GPU(s) are visible: refusing to report a {args.gpus}-GPU number\n")
+        sys.exit(2)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    argv = [a for a in sys.argv[1:] if a != "--launcher"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "16")
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
+def measure(workload, args, ctx):
+    """Times args.steps render passes of one workload on this rank's GPU (all ranks together); returns the
+    fields of the JSON line on rank 0 (None elsewhere) plus what the oracle legs need."""
     import torch
-    from raytracer_amd import (CameraConfiguration, RenderChunk, RenderSettings, Scene, SceneBuilder,
-                               create_render_chunks)
-    from raytracer_amd._ffi import RtRayCounters
+    from raytracer_amd import CameraConfiguration, RenderChunk, RenderSettings, Scene, SceneBuilder, resolve_device
+    from raytracer_amd.dist import InterleavedCompositor, reduce_accumulators, sample_range_of_rank
+    dist, rank, n_gpus, dev, device = ctx["dist"], ctx["rank"], ctx["n_gpus"], ctx["dev"], ctx["device"]
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = "RANK" in os.environ and "MASTER_ADDR" in os.environ     # launched by torch.distributed.run
-    if distributed:
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    n_gpus = world if distributed else 1
-    device = local_rank if distributed else 0
-    torch.cuda.set_device(device)
-    dev = torch.device("cuda", device)
-
-    scene_name, W, H, spp, depth, lens, params = WORKLOADS[args.workload]
+    scene_name, W, H, spp, depth, lens, params = WORKLOADS[workload]
     cfg = CameraConfiguration(W, H, lens_radius=lens)
     builder = SceneBuilder.sample(scene_name, cfg, params=params)
     scene = Scene(builder, device=device)
     settings = RenderSettings(W, H, depth, spp)
-    seed = 12345
     info = scene.info()
 
-    # ---- work split ---------------------------------------------------------
-    from raytracer_amd.dist import InterleavedCompositor, reduce_accumulators, sample_range_of_rank
-    from raytracer_amd import resolve_device
     counters = torch.zeros(4, dtype=torch.int64, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
     whole = RenderChunk(0, 0, W, H)
@@ -118,22 +137,21 @@ def main():
     def step():
         if args.mode == "tiles":
             if n_gpus == 1:
-                scene.render_chunk_device(settings, whole, seed, comp.packed.data_ptr(), None, W, 0, 0,
-                                          counters.data_ptr(), stream)
+                scene.render_chunk_device(settings, whole, SEED, comp.packed.data_ptr(), None, W, 0, 0, counters.data_ptr(), stream)
             else:           # all of this rank's strips in one launch, straight into the send buffer
-                scene.render_strips_device(settings, comp.strip_height, rank, n_gpus, seed, comp.packed.data_ptr(), None,
+                scene.render_strips_device(settings, comp.strip_height, rank, n_gpus, SEED, comp.packed.data_ptr(), None,
                                            counters.data_ptr(), stream)
                 comp.composite()
         else:
             acc.zero_()
             if s_count:
-                scene.accumulate_chunk_device(settings, whole, seed, s_first, s_count, acc.data_ptr(), counters.data_ptr(), stream)
+                scene.accumulate_chunk_device(settings, whole, SEED, s_first, s_count, acc.data_ptr(), counters.data_ptr(), stream)
             total = reduce_accumulators(acc, rank, n_gpus)
             if rank == 0:
                 resolve_device(device, total.data_ptr(), W * H, spp, frame.data_ptr(), None, stream)
 
     def barrier():
-        if distributed:
+        if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -149,124 +167,186 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    kernel_ms, launches = scene.profile_read()
+    kernel_ms, launches = scene.profile_read()       # HIP events around every render_kernel launch, on its stream
     scene.profile_enable(False)
 
     cn = counters.clone()
     local_rays = int(cn[:3].sum().item())          # this rank's rays: what its own kernel launches traced
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if distributed:
+    if dist is not None:
         dist.all_reduce(cn, op=dist.ReduceOp.SUM)
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
     primary, secondary, shadow, samples = [int(v) for v in cn.tolist()]
     rays = primary + secondary + shadow
-    rays_per_step = rays / args.steps
-
-    result = None
-    if rank == 0:
-        ms_per_step = elapsed * 1e3 / args.steps
-        value = rays / elapsed / 1e6
-        result = {
-            "metric": "Mrays/sec (whole node)", "value": round(value, 3), "unit": "Mrays/s",
-            "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": args.workload, "scene": scene_name, "width": W, "height": H,
-                       "samples_per_pixel": spp, "max_reflections": depth, "lens_radius": lens, "seed": seed,
-                       "entities": int(info.entity_count), "triangles": int(info.instanced_triangle_count),
-                       "parallelism": parallelism},
-            "msamples_per_s": round(samples / elapsed / 1e6, 3),
-            "rays_per_step": {"primary": primary // args.steps, "secondary": secondary // args.steps,
-                              "shadow": shadow // args.steps},
-        }
-
-    # ---- oracle legs on rank 0: (1) roofline statistics at any N ---------------------------------------
-    if rank == 0 and not args.no_cpu_baseline:
-        from tests.oracle import ORC_RNG_COUNTER, ORC_RNG_XORSHIFT_CHUNK, OracleScene
-        oracle = OracleScene(builder)
-        grid = (32, 32)
-        n_chunks = grid[0] * grid[1]
-        threads = min(16, os.cpu_count() or 1)
-        # (1) per-ray work of the ordered, shrinking traversal (algorithmic minimum), low spp
-        st_stats = RenderSettings(W, H, depth, min(spp, 4))
-        stride_stats = 13
-        cn_s, ms_s = oracle.render_chunks_mt(st_stats, grid, 5, stride_stats, (n_chunks - 6) // stride_stats, threads,
-                                             rng_mode=ORC_RNG_COUNTER, seed=seed, stats=True)
-        cpu_samples_per_s = cn_s.rays.samples / max(ms_s, 1e-3) * 1e3 * 2.0      # the statistics run traverses twice
-        r_s = cn_s.rays.primary + cn_s.rays.secondary + cn_s.rays.shadow
-        per_ray = {k: getattr(cn_s, "min_" + k) / r_s for k in ("nodes", "spheres", "planes", "tris", "xforms", "instances")}
-        hits_per_ray = (cn_s.rays.primary + cn_s.rays.secondary) / r_s          # shading happens per path ray
-        flops_per_ray = (per_ray["nodes"] * F_AABB + per_ray["spheres"] * F_SPH + per_ray["planes"] * F_PLANE +
-                         per_ray["tris"] * F_TRI + per_ray["xforms"] * F_XFORM + hits_per_ray * F_SHADE)
-        # on-chip gather demand per ray in the HBM layout (served by L1/L2 for these scenes)
-        gather_bytes_per_ray = (per_ray["nodes"] * B_NODE + (per_ray["spheres"] + per_ray["planes"]) * B_ENTITY +
-                                per_ray["tris"] * B_TRI + per_ray["instances"] * B_INST + B_RAY)
-        kernel_s = kernel_ms / 1e3 / max(launches, 1)
-        rays_per_launch = local_rays / max(launches, 1)     # rank 0's launches (N > 1: its share of the frame)
-        tflops = flops_per_ray * rays_per_launch / kernel_s / 1e12
-        # algorithmic HBM bytes of one launch: the scene once + one float3 segment sum per work item
-        from raytracer_amd import sample_segment
-        segs = (spp + sample_segment() - 1) // sample_segment()
-        hbm_bytes_per_launch = (int(info.device_bytes) + W * H * segs * B_PIXEL // n_gpus) * (args.steps / max(launches, 1))
-        gbs = hbm_bytes_per_launch / kernel_s / 1e9
-        traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # HBM bytes per launch from rocprofv3 --pmc passes
-        if os.path.exists(pmc_path):
-            try:
-                traffic = json.load(open(pmc_path)).get(args.workload)
-            except Exception:
-                traffic = None
-        # VALU issue time of one launch from the committed PMC pass (profiles/pmc_traffic.json "valu_insts"):
-        # every non-packed VALU wave-instruction holds its SIMD for 4 cycles; 256 CUs x 4 SIMDs at 2.4 GHz
-        valu_issue_ms = None
-        try:
-            valu_insts = json.load(open(pmc_path)).get("valu_insts", {}).get(args.workload) if n_gpus == 1 else None
-            if valu_insts:
-                valu_issue_ms = valu_insts * 4.0 / (256 * 4) / 2.4e9 * 1e3
-        except Exception:
-            valu_issue_ms = None
-        result["roofline"] = {
-            "bound": "valu", "achieved": round(tflops, 4), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(tflops / VALU_PEAK_TFLOPS, 5), "traffic": traffic if n_gpus == 1 else None,
-            "kernel": "render_kernel", "kernel_ms_avg": round(kernel_s * 1e3, 4), "launches": int(launches),
-            "flops_per_ray": round(flops_per_ray, 2),
-            "per_ray": {k: round(v, 3) for k, v in per_ray.items()}, "traversal_mismatch": int(cn_s.min_mismatch),
-            "valu_issue_ms": None if valu_issue_ms is None else round(valu_issue_ms, 3),
-            "valu_issue_frac": None if valu_issue_ms is None else round(valu_issue_ms / (kernel_s * 1e3), 4),
-        }
-        result["roofline_hbm"] = {"bound": "hbm", "achieved": round(gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                  "frac": round(gbs / HBM_PEAK_GBS, 6), "bytes_per_launch": int(hbm_bytes_per_launch),
-                                  "scene_bytes": int(info.device_bytes),
-                                  "on_chip_gather_bytes_per_ray": round(gather_bytes_per_ray, 2),
-                                  "on_chip_gather_GBps": round(gather_bytes_per_ray * rays_per_launch / kernel_s / 1e9, 1)}
-    # (2) the reference's multithreaded CPU path, bounded sample of the same frame: N = 1 only
-    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
-        # about 6e8 samples (10-20 s on 16 host threads), fewer on scenes where that would take over ~20 s
-        target = min(6.0e8, max(2.0e6, cpu_samples_per_s * 20.0))
-        stride = args.cpu_chunk_stride or max(1, int(round(W * H * spp / target)))
-        if stride > 4:          # a sparse sample: many small chunks spread over the frame instead of a few large ones
-            grid = (128, 128)
-            n_chunks = grid[0] * grid[1]
-            stride = max(1, int(round(W * H * spp / target)))
-            if stride % 128 == 0 or stride % 2 == 0:
-                stride += 1     # odd and not a multiple of the row length: the picks walk across rows and columns
-        count = (n_chunks - 1) // stride
-        cn_b, ms_b = oracle.render_chunks_mt(settings, grid, stride // 2, stride, count, threads, rng_mode=ORC_RNG_XORSHIFT_CHUNK,
-                                             seed=seed)
-        r_b = cn_b.rays.primary + cn_b.rays.secondary + cn_b.rays.shadow
-        result["cpu_baseline"] = {
-            "value": round(r_b / ms_b / 1e3, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "sample": f"{count} of {n_chunks} chunks ({grid[0]}x{grid[1]} grid, every {stride}th) of the same frame at full spp, "
-                      f"{cn_b.rays.samples} samples, {ms_b / 1e3:.1f} s; oracle/rt_oracle.cpp -O2 -ffp-contract=off, "
-                      f"{threads} std::threads pulling chunks (src/render.rs:186-224), per-chunk XorShift RNG",
-            "msamples_per_s": round(cn_b.rays.samples / ms_b / 1e3, 3),
-        }
-        result["gpu_over_cpu"] = round(result["value"] / result["cpu_baseline"]["value"], 1)
-
-    if rank == 0:
-        print(json.dumps(result))
     scene.close()
-    if distributed:
+    if rank != 0:
+        return None
+    line = {
+        "metric": "Mrays/sec (whole node)", "value": round(rays / elapsed / 1e6, 3), "unit": "Mrays/s",
+        "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / args.steps, 3),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": workload, "scene": scene_name, "width": W, "height": H,
+                   "samples_per_pixel": spp, "max_reflections": depth, "lens_radius": lens, "seed": SEED,
+                   "entities": int(info.entity_count), "triangles": int(info.instanced_triangle_count),
+                   "mode": args.mode, "parallelism": parallelism},
+        "rccl_ranks": ctx["world"] if dist is not None else 0,
+        "msamples_per_s": round(samples / elapsed / 1e6, 3),
+        "rays_per_step": {"primary": primary // args.steps, "secondary": secondary // args.steps, "shadow": shadow // args.steps},
+    }
+    return dict(line=line, builder=builder, settings=settings, info=info, kernel_ms=kernel_ms, launches=launches, local_rays=local_rays,
+                W=W, H=H, spp=spp, depth=depth, workload=workload)
+
+
+def host_threads():
+    """Threads this process may run at once (the GPU box reports the whole machine in os.cpu_count())."""
+    try:
+        allowed = len(os.sched_getaffinity(0))
+    except AttributeError:
+        allowed = os.cpu_count() or 1
+    for var in ("OMP_NUM_THREADS", "MAX_JOBS"):             # the box's CPU share, when it states one
+        try:
+            allowed = min(allowed, int(os.environ[var]))
+        except (KeyError, ValueError):
+            pass
+    return max(1, allowed)
+
+
+def oracle_legs(m, args, n_gpus):
+    """Rank 0: roofline statistics of the render kernel (any N) and the CPU baseline (N = 1)."""
+    from raytracer_amd import RenderSettings, sample_segment
+    from tests.oracle import ORC_RNG_COUNTER, ORC_RNG_XORSHIFT_CHUNK, OracleScene
+    line, W, H, spp, depth, info = m["line"], m["W"], m["H"], m["spp"], m["depth"], m["info"]
+    oracle = OracleScene(m["builder"])
+    grid = (32, 32)
+    n_chunks = grid[0] * grid[1]
+    threads_all = host_threads()
+    threads = min(16, threads_all)
+    # (1) per-ray work of the ordered, shrinking traversal (algorithmic minimum), low spp
+    st_stats = RenderSettings(W, H, depth, min(spp, 4))
+    stride_stats = 13
+    cn_s, ms_s = oracle.render_chunks_mt(st_stats, grid, 5, stride_stats, (n_chunks - 6) // stride_stats, threads,
+                                         rng_mode=ORC_RNG_COUNTER, seed=SEED, stats=True)
+    cpu_samples_per_s = cn_s.rays.samples / max(ms_s, 1e-3) * 1e3 * 2.0      # the statistics run traverses twice
+    r_s = cn_s.rays.primary + cn_s.rays.secondary + cn_s.rays.shadow
+    per_ray = {k: getattr(cn_s, "min_" + k) / r_s for k in ("nodes", "spheres", "planes", "tris", "xforms", "instances")}
+    hits_per_ray = (cn_s.rays.primary + cn_s.rays.secondary) / r_s          # shading happens per path ray
+    flops_per_ray = (per_ray["nodes"] * F_AABB + per_ray["spheres"] * F_SPH + per_ray["planes"] * F_PLANE +
+                     per_ray["tris"] * F_TRI + per_ray["xforms"] * F_XFORM + hits_per_ray * F_SHADE)
+    # on-chip gather demand per ray in the HBM layout (served by LDS/L1/L2 for these scenes)
+    gather_bytes_per_ray = (per_ray["nodes"] * B_NODE + (per_ray["spheres"] + per_ray["planes"]) * B_ENTITY +
+                            per_ray["tris"] * B_TRI + per_ray["instances"] * B_INST + B_RAY)
+    launches = max(m["launches"], 1)
+    kernel_s = m["kernel_ms"] / 1e3 / launches
+    rays_per_launch = m["local_rays"] / launches           # rank 0's launches (N > 1: its share of the frame)
+    tflops = flops_per_ray * rays_per_launch / kernel_s / 1e12
+    # algorithmic HBM bytes of one launch: the scene once + one float3 segment sum per work item
+    segs = (spp + sample_segment() - 1) // sample_segment()
+    hbm_bytes_per_launch = (int(info.device_bytes) + W * H * segs * B_PIXEL // n_gpus) * (args.steps / launches)
+    gbs = hbm_bytes_per_launch / kernel_s / 1e9
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # HBM bytes per launch from rocprofv3 --pmc passes
+    if os.path.exists(pmc_path) and n_gpus == 1:
+        try:
+            traffic = json.load(open(pmc_path)).get(m["workload"])
+        except Exception:
+            traffic = None
+    line["roofline"] = {
+        "bound": "valu", "achieved": round(tflops, 4), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "frac": round(tflops / VALU_PEAK_TFLOPS, 5), "traffic": traffic,
+        "kernel": "render_kernel", "kernel_ms_avg": round(kernel_s * 1e3, 4), "launches": int(m["launches"]),
+        "flops_per_ray": round(flops_per_ray, 2),
+        "per_ray": {k: round(v, 3) for k, v in per_ray.items()}, "traversal_mismatch": int(cn_s.min_mismatch),
+    }
+    line["roofline_hbm"] = {"bound": "hbm", "achieved": round(gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(gbs / HBM_PEAK_GBS, 6), "bytes_per_launch": int(hbm_bytes_per_launch),
+                            "scene_bytes": int(info.device_bytes),
+                            "on_chip_gather_bytes_per_ray": round(gather_bytes_per_ray, 2),
+                            "on_chip_gather_GBps": round(gather_bytes_per_ray * rays_per_launch / kernel_s / 1e9, 1)}
+    if n_gpus != 1:
+        return
+    # (2) the reference's multithreaded CPU path on a bounded sample of the same frame: chunks spread evenly over the
+    # frame, full spp, per-chunk XorShift RNG; about args.cpu_seconds of work per run, 3 runs per thread count, median.
+    target = min(3.0e8, max(1.0e6, cpu_samples_per_s * args.cpu_seconds))
+    stride = max(1, int(round(W * H * spp / target)))
+    if stride > 4:          # a sparse sample: many small chunks spread over the frame instead of a few large ones
+        grid = (128, 128)
+        n_chunks = grid[0] * grid[1]
+        if stride % 128 == 0 or stride % 2 == 0:
+            stride += 1     # odd and not a multiple of the row length: the picks walk across rows and columns
+    count = (n_chunks - 1) // stride
+
+    def timed(n_threads):
+        runs = []
+        for _ in range(3):
+            cn_b, ms_b = oracle.render_chunks_mt(m["settings"], grid, stride // 2, stride, count, n_threads,
+                                                 rng_mode=ORC_RNG_XORSHIFT_CHUNK, seed=SEED)
+            r_b = cn_b.rays.primary + cn_b.rays.secondary + cn_b.rays.shadow
+            runs.append((r_b / ms_b / 1e3, cn_b.rays.samples / ms_b / 1e3, ms_b, cn_b.rays.samples))
+        runs.sort()
+        return runs[1], [round(r[0], 3) for r in runs]
+
+    legs = {}
+    for n_threads in sorted({threads, threads_all if threads_all <= 64 else 64}):
+        med, all_runs = timed(n_threads)
+        legs[n_threads] = {"value": round(med[0], 3), "msamples_per_s": round(med[1], 3), "runs": all_runs, "seconds": round(med[2] / 1e3, 2),
+                           "samples": int(med[3])}
+    best = max(legs, key=lambda k: legs[k]["value"])
+    line["cpu_baseline"] = {
+        "value": legs[best]["value"], "unit": "Mrays/s", "cores": best, "kind": "port",
+        "sample": f"{count} of {n_chunks} chunks ({grid[0]}x{grid[1]} grid, every {stride}th) of the same frame at full spp, "
+                  f"{legs[best]['samples']} samples, {legs[best]['seconds']} s per run, median of 3; oracle/rt_oracle.cpp -O2 -ffp-contract=off, "
+                  f"std::threads pulling chunks (src/render.rs:186-224), per-chunk XorShift RNG",
+        "msamples_per_s": legs[best]["msamples_per_s"],
+        "by_threads": {str(k): v for k, v in legs.items()},
+        "host": {"os_cpu_count": os.cpu_count(), "usable_threads": threads_all},
+    }
+    line["gpu_over_cpu"] = round(line["value"] / line["cpu_baseline"]["value"], 1)
+
+
+def main():
+    args = parse_args()
+    under_launcher = "RANK" in os.environ and "MASTER_ADDR" in os.environ     # one rank of torch.distributed.run
+    if not under_launcher and (args.gpus > 1 or args.launcher):
+        launch_ranks(args)                                                    # does not return
+
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1")) if under_launcher else 1
+    rank = int(os.environ.get("RANK", "0")) if under_launcher else 0
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if under_launcher else 0
+    if world != args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}: refusing to report a {args.gpus}-GPU number\n")
+        sys.exit(2)
+    if local_rank >= torch.cuda.device_count():
+        sys.stderr.write(f"bench.py: rank {rank} has no GPU (LOCAL_RANK {local_rank}, {torch.cuda.device_count()} visible)\n")
+        sys.exit(2)
+    dist = None
+    torch.cuda.set_device(local_rank)
+    if under_launcher:
+        os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")      # RCCL's version banner must not share stdout with the JSON line
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"bench.py: process group has {dist.get_world_size()} ranks, --gpus {args.gpus}")
+    ctx = dict(dist=dist, rank=rank, world=world, n_gpus=world, device=local_rank, dev=torch.device("cuda", local_rank))
+
+    m = measure(args.workload, args, ctx)
+    target = None
+    if not args.no_target_scene and args.workload == HEADLINE:
+        target = measure(TARGET_SCENE, args, ctx)
+    if rank == 0:
+        if not args.no_cpu_baseline:
+            oracle_legs(m, args, world)
+            if target is not None:
+                oracle_legs(target, args, world)
+        result = m["line"]
+        if target is not None:
+            t = target["line"]
+            result["target_scene"] = {k: t[k] for k in ("value", "unit", "ms_per_step", "config", "msamples_per_s", "rays_per_step", "roofline",
+                                                         "roofline_hbm", "cpu_baseline", "gpu_over_cpu") if k in t}
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 
