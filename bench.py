@@ -215,7 +215,7 @@ def host_threads():
 def oracle_legs(m, args, n_gpus):
     """Rank 0: roofline statistics of the render kernel (any N) and the CPU baseline (N = 1)."""
     from raytracer_amd import RenderSettings, sample_segment
-    from tests.oracle import ORC_RNG_COUNTER, ORC_RNG_XORSHIFT_CHUNK, OracleScene
+    from tests.oracle import ORC_RNG_COUNTER_STRATIFIED, ORC_RNG_XORSHIFT_CHUNK, OracleScene
     line, W, H, spp, depth, info = m["line"], m["W"], m["H"], m["spp"], m["depth"], m["info"]
     oracle = OracleScene(m["builder"])
     grid = (32, 32)
@@ -226,7 +226,7 @@ def oracle_legs(m, args, n_gpus):
     st_stats = RenderSettings(W, H, depth, min(spp, 4))
     stride_stats = 13
     cn_s, ms_s = oracle.render_chunks_mt(st_stats, grid, 5, stride_stats, (n_chunks - 6) // stride_stats, threads,
-                                         rng_mode=ORC_RNG_COUNTER, seed=SEED, stats=True)
+                                         rng_mode=ORC_RNG_COUNTER_STRATIFIED, seed=SEED, stats=True)
     cpu_samples_per_s = cn_s.rays.samples / max(ms_s, 1e-3) * 1e3 * 2.0      # the statistics run traverses twice
     r_s = cn_s.rays.primary + cn_s.rays.secondary + cn_s.rays.shadow
     per_ray = {k: getattr(cn_s, "min_" + k) / r_s for k in ("nodes", "spheres", "planes", "tris", "xforms", "instances")}

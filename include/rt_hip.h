@@ -41,7 +41,12 @@ extern "C" {
 #define RT_E_HIP        -2   /* a HIP runtime call failed                      */
 #define RT_E_NO_DEVICE  -3   /* no GPU visible                                  */
 #define RT_E_DEPTH      -4   /* BVH deeper than the traversal stack can hold
-                                (reference: ArrayVec<State,30> panic, bvh.rs:192) */
+                                (reference: ArrayVec<State,30> panic, bvh.rs:192).
+                                Found at scene creation; a kernel that nevertheless
+                                runs out of stack or deferred-ray slots sets a
+                                sticky per-scene error: the blocking entry points
+                                return it for the call itself, the *_device ones
+                                (which only enqueue) for every LATER call on the scene */
 #define RT_E_IO         -5   /* file could not be read (sample scenes / OBJ)    */
 #define RT_E_LIMIT      -6   /* size beyond a documented maximum                */
 
@@ -231,6 +236,26 @@ RtScene* rt_scene_create(const RtSceneDesc* desc, int device);
 #define RT_DEVICE_HOST_ONLY (-1)
 void     rt_scene_destroy(RtScene* scene);
 
+/* Switches of the sampler and of the launch schedule of one scene (no reference counterpart except
+ * RT_OPT_LENS_SAMPLER 0).  Takes effect for calls that start afterwards.  Defaults can be preset through the
+ * environment, read once in rt_scene_create: RT_LENS_STRATIFY, RT_FINE_SPLIT, RT_ROUND_UNITS, RT_LENS_COC. */
+enum {
+    /* 0: the two lens draws of a sample are independent, as in the reference (implementation.rs:648-653);
+     * 1 (default): stratified - see rt_render_chunk.  Changes the image (same expectation). */
+    RT_OPT_LENS_SAMPLER = 1,
+    /* work items of a launch: -1 (default) chosen per call, 0 one pixel x 8 samples, 1 one pixel x 1 sample.
+     * Never changes a bit of the image. */
+    RT_OPT_FINE_SPLIT = 2,
+    /* 1, 2, 4, 8 (default): how many 8-sample units of a pixel share a 64-lane round.  Schedule only. */
+    RT_OPT_ROUND_UNITS = 3,
+    /* circle of confusion (pixels, default 4) from which a tile is traced in rounds of one lens cell.  Schedule only. */
+    RT_OPT_LENS_COC_PX = 4,
+    /* tests of RT_E_DEPTH: run the kernels with a traversal stack of this many entries (0 = what the trees
+     * need) and clear the scene's sticky overflow error.  Synchronises the device. */
+    RT_OPT_DEBUG_STACK_ENTRIES = 100
+};
+int rt_scene_set_option(RtScene* scene, uint32_t option, double value);
+
 /* Replaces the whole `for p in chunk.iter_pixels() { cast_rays_into_scene(..);
  * put_pixel(v3_to_rgba(..)) }` loop of src/render.rs:148-159 for one chunk
  * (chunk granularity: a per-pixel FFI call cannot feed a GPU).
@@ -245,7 +270,8 @@ void     rt_scene_destroy(RtScene* scene);
  *              inside every complete group of 16 samples (4 x 4 cells over the lens
  *              square, one sample per cell; 4 x 2 cells for a complete group of 8
  *              after the last of them): same expectation as the reference's
- *              independent draws, less noise.
+ *              independent draws, less noise (RT_OPT_LENS_SAMPLER 0 selects the
+ *              reference's distribution).
  *   counters : nullable; rays are ADDED to it.
  * Host pointers; the call blocks until the pixels are in the buffers.
  * Limits (RT_E_LIMIT): image sides <= 65535, max_reflections <= 31, at most 2^28
@@ -271,6 +297,7 @@ int rt_render_chunk_device(RtScene* scene, const RtSettings* settings,
  * (src/render.rs:186-224, 63-78): the frame is cut into horizontal strips of
  * `strip_height` rows (create_render_chunks(size,[1,n]) with equal strips) and this
  * call renders, in ONE launch, the strips strip_first, strip_first+strip_period, ...
+ * `strip_height` must be a multiple of 8 (the kernel's 8x8 ray tiles; RT_E_INVALID otherwise).
  * Outputs (device pointers, nullable) are PACKED: rt_strip_rows() rows of
  * settings.width pixels, the owned strips one after the other.  Pixels are
  * identical to those of rt_render_chunk for the same image rows. */

@@ -138,7 +138,8 @@ enum { PURPOSE_LENS = 0, PURPOSE_PATH = 1, PURPOSE_SHADOW = 2 };
 // The RNG the render loop sees.  XorShift ignores contexts (sequential stream,
 // reference semantics); the counter RNG is addressed by them.
 struct Rng {
-    int mode = ORC_RNG_XORSHIFT_CHUNK;
+    int mode = ORC_RNG_XORSHIFT_CHUNK;     // XORSHIFT_CHUNK or COUNTER (the generator); COUNTER_STRATIFIED = COUNTER + `stratified`
+    bool stratified = false;
     XorShift xs;
     // counter mode
     uint32_t key[2] = {0, 0};
@@ -1000,15 +1001,17 @@ V3 cast_one_sample(TraceCtx& cx, const RtSettings& st, uint32_t x, uint32_t y, R
     if (st.samples_per_pixel > 1) {
         rng.set_ctx(0, PURPOSE_LENS);
         float r0 = rng.next_f32(), r1 = rng.next_f32();
-        // The product's sampler (counter mode only; the reference draws the two numbers independently):
+        // ORC_RNG_XORSHIFT_CHUNK and ORC_RNG_COUNTER stop here: the reference uses the two draws as they are (:649-652).
+        // ORC_RNG_COUNTER_STRATIFIED - NOT reference semantics, the product's default sampler (RT_OPT_LENS_SAMPLER 1):
         // the lens samples are stratified, sample s in cell s mod 16 of a 4 x 4 grid over the lens square inside
         // complete groups of 16 samples (s mod 8 of 4 x 2 cells in a complete segment of 8 after them),
         // jittered inside the cell.  Same expectation, less noise.
-        if (rng.mode == ORC_RNG_COUNTER && (rng.sample / 16u + 1u) * 16u <= st.samples_per_pixel) {
+        if (!rng.stratified) { }
+        else if ((rng.sample / 16u + 1u) * 16u <= st.samples_per_pixel) {
             const uint32_t cell = rng.sample & 15u;          // complete group of 16 samples: 4 x 4 cells
             r0 = ((float)(cell & 3u) + r0) * 0.25f;
             r1 = ((float)(cell >> 2) + r1) * 0.25f;
-        } else if (rng.mode == ORC_RNG_COUNTER && (rng.sample / 8u + 1u) * 8u <= st.samples_per_pixel) {
+        } else if ((rng.sample / 8u + 1u) * 8u <= st.samples_per_pixel) {
             const uint32_t cell = rng.sample & 7u;           // complete segment of 8 after them: 4 x 2 cells
             r0 = ((float)(cell & 3u) + r0) * 0.25f;
             r1 = ((float)(cell >> 2) + r1) * 0.5f;
@@ -1053,6 +1056,8 @@ inline void v3_to_rgba(V3 c, uint8_t* out) {                                    
 }
 
 void rng_init(Rng& rng, int mode, uint64_t seed) {
+    rng.stratified = mode == ORC_RNG_COUNTER_STRATIFIED;
+    if (mode == ORC_RNG_COUNTER_STRATIFIED) mode = ORC_RNG_COUNTER;
     rng.mode = mode;
     if (mode == ORC_RNG_XORSHIFT_CHUNK) rng.xs.seed_from_u64(seed);
     else { rng.key[0] = (uint32_t)seed; rng.key[1] = (uint32_t)(seed >> 32); }
@@ -1171,10 +1176,11 @@ int orc_render_chunk(const OrcScene* s, const RtSettings* st, const RtRenderChun
     return RT_OK;
 }
 
-int orc_accumulate_chunk(const OrcScene* s, const RtSettings* st, const RtRenderChunk* ch, uint64_t seed,
+int orc_accumulate_chunk(const OrcScene* s, const RtSettings* st, const RtRenderChunk* ch, int rng_mode, uint64_t seed,
                          uint32_t sample_first, uint32_t sample_count, float* accum) {
-    if (!s || !validate_settings(st, ch) || !accum) return fail(RT_E_INVALID, "orc_accumulate_chunk: bad arguments");
-    Counters cn; Rng rng; rng_init(rng, ORC_RNG_COUNTER, seed);
+    if (!s || !validate_settings(st, ch) || !accum || (rng_mode != ORC_RNG_COUNTER && rng_mode != ORC_RNG_COUNTER_STRATIFIED))
+        return fail(RT_E_INVALID, "orc_accumulate_chunk: bad arguments");
+    Counters cn; Rng rng; rng_init(rng, rng_mode, seed);
     TraceCtx cx{*s, cn, nullptr};
     try {
         for (uint32_t y = 0; y < ch->height; y++)

@@ -34,9 +34,18 @@ enum {
     /* reference semantics: one XorShiftRng::seed_from_u64(seed) per chunk,
      * consumed sequentially in pixel order (src/render.rs:142-153)            */
     ORC_RNG_XORSHIFT_CHUNK = 0,
-    /* the product's counter-based RNG: Philox4x32-10 addressed by
-     * (seed, x, y, sample, node, purpose); independent of chunking            */
-    ORC_RNG_COUNTER = 1
+    /* reference semantics with the product's GENERATOR: every rng.random::<f32>()
+     * of the reference (lens: implementation.rs:649-650, scatter: :17-18) is a draw
+     * of a counter-based RNG, Philox4x32-10 addressed by (seed, x, y, sample, node,
+     * purpose); independent of chunking.  The product in RT_OPT_LENS_SAMPLER 0.    */
+    ORC_RNG_COUNTER = 1,
+    /* NOT a restatement of the reference: ORC_RNG_COUNTER plus the product's
+     * stratified lens sampler (the two lens draws of sample s are placed in cell
+     * s mod 16 of a 4 x 4 grid over the lens square; include/rt_hip.h,
+     * rt_render_chunk).  The product's default, RT_OPT_LENS_SAMPLER 1.  The one
+     * place the oracle follows the product instead of the reference; it exists so
+     * that the default configuration can be compared pixel by pixel too.          */
+    ORC_RNG_COUNTER_STRATIFIED = 2
 };
 
 /* Work counters (per render call, added to). "ref_*" count what the reference's
@@ -64,10 +73,10 @@ int orc_render_chunk(const OrcScene* s, const RtSettings* settings,
                      uint32_t sum_segment, int stats,
                      float* rgb_out, uint8_t* rgba_out, OrcCounters* counters);
 
-/* Sum (not mean) of the clamped samples [sample_first, +sample_count) in
- * counter mode; the checker for rt_accumulate_chunk_device. */
+/* Sum (not mean) of the clamped samples [sample_first, +sample_count) in one of
+ * the two counter modes; the checker for rt_accumulate_chunk_device. */
 int orc_accumulate_chunk(const OrcScene* s, const RtSettings* settings,
-                         const RtRenderChunk* chunk, uint64_t seed,
+                         const RtRenderChunk* chunk, int rng_mode, uint64_t seed,
                          uint32_t sample_first, uint32_t sample_count,
                          float* accum_out);
 

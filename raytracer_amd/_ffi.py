@@ -22,6 +22,8 @@ RT_MAT_LAMBERTIAN, RT_MAT_SPECULAR, RT_MAT_DIELECTRIC = 0, 1, 2
 RT_LIGHT_POINT, RT_LIGHT_LAMP, RT_LIGHT_DIRECTIONAL = 0, 1, 2
 RT_SKY_DAY, RT_SKY_BLACK = 0, 1
 RT_DEVICE_HOST_ONLY = -1
+# rt_scene_set_option
+RT_OPT_LENS_SAMPLER, RT_OPT_FINE_SPLIT, RT_OPT_ROUND_UNITS, RT_OPT_LENS_COC_PX, RT_OPT_DEBUG_STACK_ENTRIES = 1, 2, 3, 4, 100
 
 
 class RtV3(C.Structure):
@@ -171,6 +173,7 @@ HIP_PROTOTYPES = {
     "rt_scene_info": (C.c_int, [C.c_void_p, _P(RtSceneInfo)]),
     "rt_scene_bvh_order": (C.c_int64, [C.c_void_p, C.c_int64, C.c_void_p, C.c_uint64]),
     "rt_scene_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "rt_scene_set_option": (C.c_int, [C.c_void_p, C.c_uint32, C.c_double]),
     "rt_scene_profile_read": (C.c_int, [C.c_void_p, _P(C.c_double), _P(C.c_uint64)]),
 }
 

@@ -117,6 +117,10 @@ __device__ __forceinline__ Word4 ldw(const Word4* p) {
 // by the exact (t, rank) order, so a candidate visited needlessly never changes the result; the bound never
 // exceeds the ray's t_max, so no box is entered that the reference's own test would reject.
 #define RT_CULL_SLACK 1.0009765625f
+// Sticky device-side error word (host-mapped, RtScene::dev_error): a capacity that the host sized from the trees turned
+// out too small.  Never expected; reported as RT_E_DEPTH instead of a silently wrong image.
+#define RT_DEVERR_STACK   1u      /* traversal stack full: a deferred subtree would have been dropped */
+#define RT_DEVERR_PENDING 2u      /* deferred-ray list full: a refraction ray would have been dropped */
 
 // ===========================================================================
 // counter-based RNG: Philox4x32-10 (Random123), counter = (x | y<<16, sample,
@@ -213,7 +217,7 @@ __device__ __forceinline__ void ray_to_entity(const DevSceneView& S, const Word4
 // Sphere::hit / Plane::hit / MeshBvhRoot::try_hit (sphere.rs:36-53, plane.rs:59-90,
 // mesh.rs:92-99).  `stack` is this lane's LDS column (stride RT_BLOCK dwords).
 __device__ __forceinline__ void trace(const DevSceneView& S, const F3 wo, const F3 wd, const float t_min, const float t_max,
-                                      uint32_t* stack, const uint32_t stack_cap, Hit& best) {
+                                      uint32_t* stack, const uint32_t stack_cap, uint32_t* error_flag, Hit& best) {
     best.t = t_max; best.ent = RT_NONE; best.tri = RT_NONE; best.erank = 0;
     float best_t = t_max;                 // culling bound; primitives test against [t_min, t_max]
 
@@ -249,6 +253,7 @@ __device__ __forceinline__ void trace(const DevSceneView& S, const F3 wo, const 
                 const uint32_t far_ref = left_first ? r.u[1] : r.u[0];
                 cur = left_first ? r.u[0] : r.u[1];
                 if (sp < stack_cap) stack[(sp++) * RT_BLOCK] = far_ref;
+                else *error_flag = RT_DEVERR_STACK;
             } else if (hl || hr) cur = hl ? r.u[0] : r.u[1];
             else cur = pop();
         }
@@ -330,8 +335,10 @@ __device__ __forceinline__ void trace(const DevSceneView& S, const F3 wo, const 
                 const F3 einv = f3(1.0f / ed.x, 1.0f / ed.y, 1.0f / ed.z);
                 float e;
                 if (slab(m1.f[0], m1.f[1], m1.f[2], m1.f[3], m2.f[0], m2.f[1], eo, einv, t_min, best_t, e)) {      // entity space: exact box
-                    if (k + 1 < count && sp < stack_cap)
-                        stack[(sp++) * RT_BLOCK] = RT_REF_LEAF_BIT | ((count - k - 2) << RT_REF_COUNT_SHIFT) | (ei + 1);
+                    if (k + 1 < count) {
+                        if (sp < stack_cap) stack[(sp++) * RT_BLOCK] = RT_REF_LEAF_BIT | ((count - k - 2) << RT_REF_COUNT_SHIFT) | (ei + 1);
+                        else *error_flag = RT_DEVERR_STACK;
+                    }
                     inst_sp = sp;
                     o = eo; d = ed; inv = einv;
                     tri_base = m0.u[1];
@@ -542,6 +549,8 @@ struct RenderParams {
     uint32_t round_units_shift;                     // log2 of the units whose samples share a round (divides unit_count)
     float lens_coc_px;                              // classify_kernel: circle of confusion (pixels) from which a tile's rounds go by lens cell
     uint32_t lens_rounds;                           // tiles flagged by classify_kernel may run rounds of one sample index (8 units x 8 pixels)
+    uint32_t lens_stratify;                         // 1: stratified lens samples (the product's sampler); 0: two independent draws (implementation.rs:648-653)
+    uint32_t* error_flag;                           // sticky device-side error word (RT_DEVERR_* bits), read back by the host entry points
     uint32_t tiles_x, pix_slots;                    // 8x8 tiling of the chunk; pix_slots = tiles*64
     float* partial;                                 // [unit_count][tile][64][3] sums of the clamped samples of each unit (8x8 tiles of the chunk)
     unsigned long long* counters;                   // RtRayCounters on the device (nullable)
@@ -808,6 +817,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                         if (refract_limit == 0u) sample_col = sample_col + (cw_ * color_sky(S, refr_d));   // :562-564
                         else if (!(cast_refl && reflect_limit != 0u)) refr_in_place = true;
                         else if (npend < RT_PENDING_MAX) { Pending& q = pend[npend++]; q.o = hr.p; q.d = refr_d; q.w = cw_; q.limit = refract_limit; q.node = parent * 2u + 1u; }
+                        else *P.error_flag = RT_DEVERR_PENDING;
                     }
                     if (cast_refl) {
                         const F3 cw_ = wa * reflection_intensity;
@@ -934,7 +944,8 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                         // (complete groups of 16 samples; 4 x 2 cells for a complete segment of 8 after them), jittered inside the cell (the reference draws them
                         // independently: same expectation, less noise - and the rays of one sample index of
                         // neighbouring pixels leave the lens close together, see the round shapes above).
-                        if (((s >> 4) + 1u) * 16u <= P.spp) {                              // a complete group of 16 samples: 4 x 4 cells
+                        if (!P.lens_stratify) { }                                           // RT_OPT_LENS_SAMPLER 0: the reference's two independent draws
+                        else if (((s >> 4) + 1u) * 16u <= P.spp) {                         // a complete group of 16 samples: 4 x 4 cells
                             const uint32_t cell = s & 15u;
                             r0 = ((float)(cell & 3u) + r0) * 0.25f; r1 = ((float)(cell >> 2) + r1) * 0.25f;
                         } else if (((s >> RT_SEGMENT_SHIFT) + 1u) * RT_SAMPLE_SEGMENT <= P.spp) {   // a complete segment of 8 after them: 4 x 2 cells
@@ -1016,6 +1027,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                         const uint32_t far_ref = left_first ? nr.u[1] : nr.u[0];
                         cur = left_first ? nr.u[0] : nr.u[1];
                         if (sp < stack_cap) stack[(sp++) * RT_BLOCK] = far_ref;
+                        else *P.error_flag = RT_DEVERR_STACK;
                     } else if (hl || hr) cur = hl ? nr.u[0] : nr.u[1];
                     else cur = pop();
                 }
@@ -1102,8 +1114,10 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                                 const F3 einv = f3(1.0f / ed.x, 1.0f / ed.y, 1.0f / ed.z);
                                 float e;
                                 if (slab(m1.f[0], m1.f[1], m1.f[2], m1.f[3], m2.f[0], m2.f[1], eo, einv, t_min, best_t, e)) {
-                                    if (k + 1 < count && sp < stack_cap)
-                                        stack[(sp++) * RT_BLOCK] = RT_REF_LEAF_BIT | ((count - k - 2) << RT_REF_COUNT_SHIFT) | (ei + 1);
+                                    if (k + 1 < count) {
+                                        if (sp < stack_cap) stack[(sp++) * RT_BLOCK] = RT_REF_LEAF_BIT | ((count - k - 2) << RT_REF_COUNT_SHIFT) | (ei + 1);
+                                        else *P.error_flag = RT_DEVERR_STACK;
+                                    }
                                     inst_sp = sp;
                                     o = eo; d = ed; inv = einv;
                                     tri_base = m0.u[1];
@@ -1236,7 +1250,7 @@ classify_kernel(const DevSceneView S, const RenderParams P, uint32_t n_tiles, ui
         pixel_uv(P, px, py, pu, pv);
         gen_camera_ray(S, pu, pv, 0.0f, 0.0f, o, d);
         Hit h;
-        trace(S, o, d, RT_BIAS, RT_F32_MAX, stack, S.stack_entries, h);
+        trace(S, o, d, RT_BIAS, RT_F32_MAX, stack, S.stack_entries, P.error_flag, h);
         if (h.ent != RT_NONE) {
             const Word4 m0 = ldw(S.materials[ldw(S.entities[h.ent].w + 1).u[3]].w);
             cls = m0.u[0] == RT_MAT_DIELECTRIC ? 0u : ((m0.u[0] == RT_MAT_SPECULAR || m0.f[1] > 0.0f) ? 1u : 2u);
@@ -1297,7 +1311,7 @@ primary_kernel(const DevSceneView S, const RenderParams P, float* t_out, float* 
     pixel_uv(P, P.left + x, P.top + y, pu, pv);
     gen_camera_ray(S, pu, pv, 0.0f, 0.0f, o, d);
     Hit h;
-    trace(S, o, d, RT_BIAS, RT_F32_MAX, stack, S.stack_entries, h);
+    trace(S, o, d, RT_BIAS, RT_F32_MAX, stack, S.stack_entries, P.error_flag, h);
     float t = -1.0f; F3 n = f3(0, 0, 0); int32_t e = -1, tri = -1;
     if (h.ent != RT_NONE) { HitRec hr; resolve_hit(S, o, d, h, hr); t = h.t; n = hr.normal; e = hr.entity_index; tri = hr.tri_index; }
     if (t_out) t_out[i] = t;
@@ -1317,6 +1331,14 @@ int set_error(int code, const std::string& msg) { g_error = msg; return code; }
     do {                                                                                                   \
         hipError_t _e = (expr);                                                                            \
         if (_e != hipSuccess) return set_error(RT_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+// After work or copies were enqueued on `stream`, a failing call must not return while they can still
+// write the caller's buffers or this function's locals: drain the stream first.
+#define HIP_TRY_SYNC(expr, stream)                                                                         \
+    do {                                                                                                   \
+        hipError_t _e = (expr);                                                                            \
+        if (_e != hipSuccess) { (void)hipStreamSynchronize(stream); return set_error(RT_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); } \
     } while (0)
 
 struct DeviceBuffer {
@@ -1348,8 +1370,22 @@ struct Workspace {
 
 #define RT_MAX_WORKSPACES 8
 
+// Switches of the schedule and the sampler (rt_scene_set_option).  Their defaults can be preset through the
+// environment, which is read ONCE, in rt_scene_create: RT_LENS_STRATIFY, RT_FINE_SPLIT, RT_ROUND_UNITS, RT_LENS_COC.
+struct SceneOptions {
+    int lens_stratify = 1;          // RT_OPT_LENS_SAMPLER
+    int fine_split = -1;            // RT_OPT_FINE_SPLIT: -1 automatic, 0 whole segments, 1 single samples
+    int round_units = 8;            // RT_OPT_ROUND_UNITS
+    float lens_coc_px = 4.0f;       // RT_OPT_LENS_COC_PX (4 px measured best; 3..8 within 1 %)
+    uint32_t debug_stack_entries = 0;   // RT_OPT_DEBUG_STACK_ENTRIES: 0 = what the trees need
+};
+
 struct RtScene {
     int device = 0;
+    std::mutex opt_lock;
+    SceneOptions opt;               // every call works on a snapshot taken under opt_lock
+    uint32_t* dev_error_host = nullptr;   // host-mapped word the kernels set on a capacity overflow (RT_DEVERR_*): readable without a sync
+    uint32_t* dev_error_dev = nullptr;
     DevSceneView view{};
     RtSceneInfo info{};
     std::vector<uint32_t> tlas_order;
@@ -1418,9 +1454,18 @@ int upload(RtScene* s, const std::vector<T>& v, const T** dst) {
     return RT_OK;
 }
 
+// The kernels' sticky error word (host-mapped: no synchronisation needed to look at it).
+int check_device_error(const RtScene* scene) {
+    const uint32_t e = scene->dev_error_host ? *(volatile const uint32_t*)scene->dev_error_host : 0u;
+    if (e == 0u) return RT_OK;
+    return set_error(RT_E_DEPTH, (e & RT_DEVERR_STACK) ? "a render kernel ran out of traversal stack (BVH deeper than the scene build accounted for): pixels of that launch are incomplete"
+                                                       : "a render kernel ran out of deferred-ray slots: pixels of that launch are incomplete");
+}
+
 int validate_call(const RtScene* scene, const RtSettings* st, const RtRenderChunk* ch) {
     if (!scene || !st || !ch) return set_error(RT_E_INVALID, "null argument");
     if (scene->device == RT_DEVICE_HOST_ONLY) return set_error(RT_E_NO_DEVICE, "scene was created host-only (RT_DEVICE_HOST_ONLY): nothing to render on");
+    if (int rc = check_device_error(scene)) return rc;      // sticky: an earlier launch on this scene overflowed a capacity
     if (st->width == 0 || st->height == 0 || st->samples_per_pixel == 0) return set_error(RT_E_INVALID, "RenderSettings: width, height and samples_per_pixel must be > 0");
     if (st->width > 65535 || st->height > 65535) return set_error(RT_E_LIMIT, "RenderSettings: image sides are limited to 65535 (RNG counter packs x | y<<16)");
     if (st->max_reflections > RT_MAX_REFLECTIONS) return set_error(RT_E_LIMIT, "RenderSettings: max_reflections is limited to 31 (recursion-tree node id is 32 bit)");
@@ -1456,8 +1501,10 @@ int enqueue_accumulate(RtScene* scene, Workspace& ws, const RtSettings* st, cons
     // blocks would not even occupy the resident waves and no other host call is rendering on this
     // scene at the same time (concurrent chunk calls fill the GPU together).
     const uint64_t coarse_blocks = (uint64_t)(pix_slots / 64) * nseg;
+    SceneOptions opt;
+    { std::lock_guard<std::mutex> og(scene->opt_lock); opt = scene->opt; }
     bool fine = coarse_blocks < (uint64_t)scene->grid_blocks * (RT_BLOCK / 64) && scene->host_calls_in_flight.load() <= 1;
-    if (const char* e = getenv("RT_FINE_SPLIT")) fine = atoi(e) != 0;                    // experiments / tests: force either split
+    if (opt.fine_split >= 0) fine = opt.fine_split != 0;                                 // RT_OPT_FINE_SPLIT (experiments / tests): force either split
     const uint32_t unit_len = fine ? 1u : RT_SAMPLE_SEGMENT;
     // segments per launch: keep the scratch below ~2 GiB (a 4K frame then still runs 16 units per launch)
     const uint32_t units_per_seg = RT_SAMPLE_SEGMENT / unit_len;
@@ -1477,15 +1524,18 @@ int enqueue_accumulate(RtScene* scene, Workspace& ws, const RtSettings* st, cons
     P.partial = (float*)ws.partial.p;
     P.counters = counters_dev;
     P.strip_h = il.strip_h; P.strip_period_rows = il.period_rows; P.strip_first_row = il.first_row;
-    // RT_LENS_COC: circle of confusion in pixels from which a tile runs lens-cell rounds (a huge value turns them off)
-    { const char* e = getenv("RT_LENS_COC"); P.lens_coc_px = e ? (float)atof(e) : 4.0f; }      // (4 px measured best; 3..8 within 1 %)
+    P.lens_coc_px = opt.lens_coc_px;      // circle of confusion in pixels from which a tile runs lens-cell rounds (a huge value turns them off)
+    P.lens_stratify = opt.lens_stratify ? 1u : 0u;
+    P.error_flag = scene->dev_error_dev;
+    DevSceneView view = scene->view;
+    if (opt.debug_stack_entries && opt.debug_stack_entries < view.stack_entries) view.stack_entries = opt.debug_stack_entries;      // (tests of RT_E_DEPTH)
     // expensive tiles first (whole-segment launches over enough tiles to have a tail worth hiding)
     const uint32_t n_tiles = pix_slots / 64;
     static const bool order_tiles = []() { const char* e = getenv("RT_TILE_ORDER"); return !e || atoi(e) != 0; }();
     if (!fine && order_tiles && n_tiles >= 256) {
         if ((rc = ws.order.ensure((size_t)n_tiles * 8 + 16))) return rc;
         uint32_t* tile_bin = (uint32_t*)ws.order.p; uint32_t* tile_order = tile_bin + n_tiles + 4;      // [-1] = expensive-tile count
-        hipLaunchKernelGGL(classify_kernel, dim3((n_tiles * 16 + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), scene->stack_lds_bytes, stream, scene->view, P,
+        hipLaunchKernelGGL(classify_kernel, dim3((n_tiles * 16 + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), scene->stack_lds_bytes, stream, view, P,
                            n_tiles, tile_bin);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t*)tile_bin, n_tiles, tile_order);
@@ -1500,14 +1550,14 @@ int enqueue_accumulate(RtScene* scene, Workspace& ws, const RtSettings* st, cons
                                                                                                     : sample_first + sample_count;     // exclusive
         P.unit_first = s_lo / unit_len; P.unit_count = (s_hi - 1) / unit_len - P.unit_first + 1;
         {
-            // up to 8 units share their rounds (64 samples of one pixel side by side); RT_ROUND_UNITS = 1 / 2 / 4 lowers the cap (experiments, tests)
-            const char* e = getenv("RT_ROUND_UNITS");
-            const int cap = e ? atoi(e) : 8;
+            // up to 8 units share their rounds (64 samples of one pixel side by side); RT_OPT_ROUND_UNITS = 1 / 2 / 4 lowers the cap (experiments, tests)
+            const int cap = opt.round_units;
             const uint32_t max_shift = cap >= 8 ? 3u : cap >= 4 ? 2u : cap >= 2 ? 1u : 0u;
             P.round_units_shift = 0;
             P.lens_rounds = P.tile_order != nullptr;          // (whole-segment units over enough tiles: the tiles are classified)
             while (!fine && P.round_units_shift < max_shift && P.unit_count % (2u << P.round_units_shift) == 0) P.round_units_shift++;
-            if (P.round_units_shift != 3u) P.lens_rounds = 0u;
+            // (without the stratified sampler the samples of one index do not share a lens cell: nothing to gain from that round shape)
+            if (P.round_units_shift != 3u || !P.lens_stratify) P.lens_rounds = 0u;
         }
         const uint64_t items = (uint64_t)P.pix_slots * P.unit_count;
         uint64_t blocks = (items + RT_BLOCK - 1) / RT_BLOCK;
@@ -1535,7 +1585,7 @@ int enqueue_accumulate(RtScene* scene, Workspace& ws, const RtSettings* st, cons
                                                RT_K8(false, false, true),  RT_K8(true, false, true),  RT_K8(false, true, true),  RT_K8(true, true, true)};
 #undef RT_K8
 #undef RT_K
-            const DevSceneView& v = scene->view;
+            const DevSceneView& v = view;
             const bool dof = v.coc_rel_max * (float)st->width > P.lens_coc_px;       // (inf x width = inf: unbounded scenes keep both round shapes)
             int which = (v.mesh_entities ? 1 : 0) | (v.sphere_entities ? 2 : 0) | (v.plane_entities ? 4 : 0) | (v.general_xforms ? 8 : 0) | (v.rich_shading ? 16 : 0) |
                         (dof ? 32 : 0);
@@ -1543,7 +1593,7 @@ int enqueue_accumulate(RtScene* scene, Workspace& ws, const RtSettings* st, cons
             static const bool show_traits = getenv("RT_DEBUG_TRAITS") != nullptr;      // diagnostics: which instantiation a scene runs
             if (show_traits) fprintf(stderr, "traits: which=%d loose=%u any_hit=%u lds_nodes=%u\n", which, v.loose_boxes, v.shadow_any_hit, v.lds_nodes);
             const Kernel kernel = v.loose_boxes ? render_kernel<true, true, true, true, true, true, true> : kernels[which];
-            hipLaunchKernelGGL(kernel, dim3((uint32_t)blocks), dim3(RT_BLOCK), scene->lds_bytes, stream, scene->view, P);
+            hipLaunchKernelGGL(kernel, dim3((uint32_t)blocks), dim3(RT_BLOCK), scene->lds_bytes, stream, view, P);
         }
         HIP_TRY(hipGetLastError());
 #ifdef RT_PHASE_STATS
@@ -1618,7 +1668,43 @@ RtScene* rt_scene_create(const RtSceneDesc* desc, int device) {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_kernel<true, true, true, true, true, true, true>, RT_BLOCK, s->lds_bytes) != hipSuccess || per_cu < 1) per_cu = 1;
     s->grid_blocks = prop.multiProcessorCount * per_cu;
     if (s->shared.init(false)) return fail();
+    if (hipHostMalloc((void**)&s->dev_error_host, 64, hipHostMallocMapped) != hipSuccess) { s->dev_error_host = nullptr; set_error(RT_E_HIP, "hipHostMalloc (error word) failed"); return fail(); }
+    *s->dev_error_host = 0u;
+    if (hipHostGetDevicePointer((void**)&s->dev_error_dev, s->dev_error_host, 0) != hipSuccess) { set_error(RT_E_HIP, "hipHostGetDevicePointer failed"); return fail(); }
+    // defaults of the options from the environment, read once
+    if (const char* e = getenv("RT_LENS_STRATIFY")) s->opt.lens_stratify = atoi(e) != 0;
+    if (const char* e = getenv("RT_FINE_SPLIT")) s->opt.fine_split = atoi(e) != 0;
+    if (const char* e = getenv("RT_ROUND_UNITS")) s->opt.round_units = atoi(e);
+    if (const char* e = getenv("RT_LENS_COC")) s->opt.lens_coc_px = (float)atof(e);
     return s;
+}
+
+int rt_scene_set_option(RtScene* scene, uint32_t option, double value) {
+    if (!scene) return set_error(RT_E_INVALID, "null scene");
+    std::lock_guard<std::mutex> og(scene->opt_lock);
+    switch (option) {
+        case RT_OPT_LENS_SAMPLER:
+            if (value != 0.0 && value != 1.0) return set_error(RT_E_INVALID, "RT_OPT_LENS_SAMPLER: 0 (reference) or 1 (stratified)");
+            scene->opt.lens_stratify = (int)value; return RT_OK;
+        case RT_OPT_FINE_SPLIT:
+            if (value != -1.0 && value != 0.0 && value != 1.0) return set_error(RT_E_INVALID, "RT_OPT_FINE_SPLIT: -1 (automatic), 0 or 1");
+            scene->opt.fine_split = (int)value; return RT_OK;
+        case RT_OPT_ROUND_UNITS:
+            if (value != 1.0 && value != 2.0 && value != 4.0 && value != 8.0) return set_error(RT_E_INVALID, "RT_OPT_ROUND_UNITS: 1, 2, 4 or 8");
+            scene->opt.round_units = (int)value; return RT_OK;
+        case RT_OPT_LENS_COC_PX:
+            if (!(value >= 0.0)) return set_error(RT_E_INVALID, "RT_OPT_LENS_COC_PX: a circle of confusion in pixels, >= 0");
+            scene->opt.lens_coc_px = (float)value; return RT_OK;
+        case RT_OPT_DEBUG_STACK_ENTRIES:
+            if (!(value >= 0.0 && value <= 1024.0)) return set_error(RT_E_INVALID, "RT_OPT_DEBUG_STACK_ENTRIES: 0 (as built) .. 1024");
+            scene->opt.debug_stack_entries = (uint32_t)value;
+            if (scene->dev_error_host) {          // also re-arms the sticky error word (no launch may be in flight)
+                if (scene->device != RT_DEVICE_HOST_ONLY) { HIP_TRY(hipSetDevice(scene->device)); HIP_TRY(hipDeviceSynchronize()); }
+                *scene->dev_error_host = 0u;
+            }
+            return RT_OK;
+        default: return set_error(RT_E_INVALID, "rt_scene_set_option: unknown option");
+    }
 }
 
 void rt_scene_destroy(RtScene* s) {
@@ -1629,6 +1715,7 @@ void rt_scene_destroy(RtScene* s) {
     for (auto& w : s->pool) w->release();
     s->shared.release();
     for (void* p : s->allocations) (void)hipFree(p);
+    if (s->dev_error_host) (void)hipHostFree(s->dev_error_host);
     delete s;
 }
 
@@ -1667,14 +1754,15 @@ int rt_render_chunk(RtScene* scene, const RtSettings* st, const RtRenderChunk* c
     if (lease.rc) return lease.rc;
     Workspace& ws = *lease.ws;
     if ((rc = ws.out_rgb.ensure(npix * 12)) || (rc = ws.out_rgba.ensure(npix * 4))) return rc;
-    HIP_TRY(hipMemsetAsync(ws.ctrl.p, 0, sizeof(RtRayCounters), ws.stream));
+    HIP_TRY_SYNC(hipMemsetAsync(ws.ctrl.p, 0, sizeof(RtRayCounters), ws.stream), ws.stream);
     rc = render_chunk_device_on(scene, ws, st, ch, seed, ws.out_rgb.p, ws.out_rgba.p, ch->width, 0, 0, ws.ctrl.p, ws.stream);
     if (rc) { (void)hipStreamSynchronize(ws.stream); return rc; }
     RtRayCounters c{};
-    if (rgb_out) HIP_TRY(hipMemcpyAsync(rgb_out, ws.out_rgb.p, npix * 12, hipMemcpyDeviceToHost, ws.stream));
-    if (rgba_out) HIP_TRY(hipMemcpyAsync(rgba_out, ws.out_rgba.p, npix * 4, hipMemcpyDeviceToHost, ws.stream));
-    HIP_TRY(hipMemcpyAsync(&c, ws.ctrl.p, sizeof(c), hipMemcpyDeviceToHost, ws.stream));
+    if (rgb_out) HIP_TRY_SYNC(hipMemcpyAsync(rgb_out, ws.out_rgb.p, npix * 12, hipMemcpyDeviceToHost, ws.stream), ws.stream);
+    if (rgba_out) HIP_TRY_SYNC(hipMemcpyAsync(rgba_out, ws.out_rgba.p, npix * 4, hipMemcpyDeviceToHost, ws.stream), ws.stream);
+    HIP_TRY_SYNC(hipMemcpyAsync(&c, ws.ctrl.p, sizeof(c), hipMemcpyDeviceToHost, ws.stream), ws.stream);      // (`c` is a local: never return with this in flight)
     HIP_TRY(hipStreamSynchronize(ws.stream));
+    if ((rc = check_device_error(scene))) return rc;
     if (counters) { counters->primary += c.primary; counters->secondary += c.secondary; counters->shadow += c.shadow; counters->samples += c.samples; }
     return RT_OK;
 }
@@ -1694,6 +1782,8 @@ int rt_render_strips_device(RtScene* scene, const RtSettings* st, uint32_t strip
     if (!st) return set_error(RT_E_INVALID, "null argument");
     const int rows = rt_strip_rows(st->height, strip_height, strip_first, strip_period);
     if (rows < 0) return set_error(RT_E_INVALID, "rt_render_strips_device: strip_height and strip_period must be > 0, strip_first < strip_period");
+    // the kernel maps a whole 8x8 ray tile through the strip interleave by its first row: a strip must hold whole tile rows
+    if (strip_height % 8u != 0u) return set_error(RT_E_INVALID, "rt_render_strips_device: strip_height must be a multiple of 8 (the kernel's 8x8 ray tiles)");
     if (rows == 0) return RT_OK;                         // this rank owns no rows of so small an image
     RtRenderChunk local{0, 0, st->width, (uint32_t)rows};   // packed local rows; validated against a frame that tall
     RtSettings probe = *st; probe.height = probe.height > (uint32_t)rows ? probe.height : (uint32_t)rows;
@@ -1750,15 +1840,21 @@ int rt_primary_hits(RtScene* scene, const RtSettings* st, const RtRenderChunk* c
     RenderParams P{};
     P.width = st->width; P.height = st->height; P.max_reflections = st->max_reflections; P.spp = 1;
     P.left = ch->left; P.top = ch->top; P.cw = ch->width; P.ch = ch->height;
+    P.error_flag = scene->dev_error_dev;
+    DevSceneView view = scene->view;
+    {
+        std::lock_guard<std::mutex> og(scene->opt_lock);
+        if (scene->opt.debug_stack_entries && scene->opt.debug_stack_entries < view.stack_entries) view.stack_entries = scene->opt.debug_stack_entries;
+    }
     hipLaunchKernelGGL(primary_kernel, dim3((uint32_t)((npix + RT_BLOCK - 1) / RT_BLOCK)), dim3(RT_BLOCK), scene->stack_lds_bytes, ws.stream,
-                       scene->view, P, d_t, d_n, d_e, d_tri);
-    HIP_TRY(hipGetLastError());
-    if (t_out) HIP_TRY(hipMemcpyAsync(t_out, d_t, npix * 4, hipMemcpyDeviceToHost, ws.stream));
-    if (normal_out) HIP_TRY(hipMemcpyAsync(normal_out, d_n, npix * 12, hipMemcpyDeviceToHost, ws.stream));
-    if (entity_out) HIP_TRY(hipMemcpyAsync(entity_out, d_e, npix * 4, hipMemcpyDeviceToHost, ws.stream));
-    if (tri_out) HIP_TRY(hipMemcpyAsync(tri_out, d_tri, npix * 4, hipMemcpyDeviceToHost, ws.stream));
+                       view, P, d_t, d_n, d_e, d_tri);
+    HIP_TRY_SYNC(hipGetLastError(), ws.stream);
+    if (t_out) HIP_TRY_SYNC(hipMemcpyAsync(t_out, d_t, npix * 4, hipMemcpyDeviceToHost, ws.stream), ws.stream);
+    if (normal_out) HIP_TRY_SYNC(hipMemcpyAsync(normal_out, d_n, npix * 12, hipMemcpyDeviceToHost, ws.stream), ws.stream);
+    if (entity_out) HIP_TRY_SYNC(hipMemcpyAsync(entity_out, d_e, npix * 4, hipMemcpyDeviceToHost, ws.stream), ws.stream);
+    if (tri_out) HIP_TRY_SYNC(hipMemcpyAsync(tri_out, d_tri, npix * 4, hipMemcpyDeviceToHost, ws.stream), ws.stream);
     HIP_TRY(hipStreamSynchronize(ws.stream));
-    return RT_OK;
+    return check_device_error(scene);
 }
 
 int rt_create_render_chunks(uint32_t width, uint32_t height, uint32_t count_x, uint32_t count_y, RtRenderChunk* out, uint32_t capacity) {

@@ -267,6 +267,14 @@ class Scene:
             raise RtError(rc, self._lib.rt_last_error().decode())
         return rc
 
+    OPTIONS = {"lens_sampler": _ffi.RT_OPT_LENS_SAMPLER, "fine_split": _ffi.RT_OPT_FINE_SPLIT, "round_units": _ffi.RT_OPT_ROUND_UNITS,
+               "lens_coc_px": _ffi.RT_OPT_LENS_COC_PX, "debug_stack_entries": _ffi.RT_OPT_DEBUG_STACK_ENTRIES}
+
+    def set_option(self, name, value):
+        """rt_scene_set_option: "lens_sampler" 0 = the reference's independent lens draws / 1 = stratified (default);
+        "fine_split" -1 / 0 / 1, "round_units" 1 / 2 / 4 / 8 and "lens_coc_px" only change the schedule."""
+        self._check(self._lib.rt_scene_set_option(self._h, self.OPTIONS[name], float(value)))
+
     def info(self):
         out = RtSceneInfo()
         self._check(self._lib.rt_scene_info(self._h, C.byref(out)))

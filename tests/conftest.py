@@ -19,3 +19,11 @@ def _built_libraries():
     from tests import oracle
     oracle.lib()
     yield
+
+
+@pytest.fixture(params=["reference", "stratified"])
+def lens_mode(request):
+    """One-to-one pixel comparisons run under both lens samplers: "reference" = the reference's two independent lens draws
+    (implementation.rs:648-653; oracle ORC_RNG_COUNTER, product RT_OPT_LENS_SAMPLER 0) and "stratified" = the product's
+    default sampler (oracle ORC_RNG_COUNTER_STRATIFIED, the one labelled product extension of the oracle)."""
+    return request.param

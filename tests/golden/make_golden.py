@@ -19,11 +19,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
 from raytracer_amd import CameraConfiguration, RenderChunk, RenderSettings, SceneBuilder, create_render_chunks  # noqa: E402
-from tests.oracle import ORC_RNG_COUNTER, ORC_RNG_XORSHIFT_CHUNK, OracleScene  # noqa: E402
+from tests.oracle import LENS_MODES, ORC_RNG_COUNTER, ORC_RNG_XORSHIFT_CHUNK, OracleScene  # noqa: E402
 
 PRIMARY = [("Random Spheres", 64, 36), ("Mesh", 64, 36), ("Simple", 48, 27), ("Mirrors", 48, 27), ("Dreadnaught", 48, 27)]
 IMAGES = [("Random Spheres", 48, 27, 4, 8), ("Mesh", 48, 27, 2, 8), ("Simple", 32, 18, 2, 5), ("Mirrors", 32, 18, 2, 10),
           ("Dreadnaught", 32, 18, 1, 5)]
+# enough samples for complete groups of 16 / 8 lens samples, where the reference's sampler (ORC_RNG_COUNTER) and the product's
+# stratified one (ORC_RNG_COUNTER_STRATIFIED) differ: both are pinned.  (IMAGES have fewer than 8 samples: the two modes coincide.)
+IMAGES_DOF = [("Random Spheres", 48, 27, 24, 8), ("Mesh", 48, 27, 19, 8)]
 SEED = 12345
 
 
@@ -52,6 +55,12 @@ def main():
             part, _, _ = o.render_chunk(st, c, ORC_RNG_XORSHIFT_CHUNK, SEED)
             ref[c.top:c.top + c.height, c.left:c.left + c.width] = part
         out[f"image/{k}/rgb_xorshift_2x2"] = ref
+    for name, w, h, spp, depth in IMAGES_DOF:
+        o = OracleScene(SceneBuilder.sample(name, CameraConfiguration(w, h, lens_radius=0.1)))
+        for mode, (rng_mode, _) in LENS_MODES.items():
+            rgb, _, cn = o.render_chunk(RenderSettings(w, h, depth, spp), RenderChunk(0, 0, w, h), rng_mode, SEED, sum_segment=8)
+            out[f"image_dof/{key(name)}/{mode}/rgb"] = rgb
+            out[f"image_dof/{key(name)}/{mode}/rays"] = np.array([cn.rays.primary, cn.rays.secondary, cn.rays.shadow, cn.rays.samples], dtype=np.int64)
     np.savez_compressed(os.path.join(HERE, "oracle_golden.npz"), **out)
     print("wrote", len(out), "arrays")
 

@@ -15,7 +15,9 @@ from raytracer_amd._ffi import RtCamera, RtLight, RtMeshTri, RtRayCounters, RtRe
 ORACLE_DIR = os.path.join(_ffi.REPO_ROOT, "oracle")
 ORACLE_LIB = os.path.join(ORACLE_DIR, "librt_oracle.so")
 
-ORC_RNG_XORSHIFT_CHUNK, ORC_RNG_COUNTER = 0, 1
+ORC_RNG_XORSHIFT_CHUNK, ORC_RNG_COUNTER, ORC_RNG_COUNTER_STRATIFIED = 0, 1, 2
+# one-to-one pixel comparison runs in both lens-sampler modes: (oracle rng mode, product RT_OPT_LENS_SAMPLER)
+LENS_MODES = {"reference": (ORC_RNG_COUNTER, 0), "stratified": (ORC_RNG_COUNTER_STRATIFIED, 1)}
 PURPOSE_LENS, PURPOSE_PATH, PURPOSE_SHADOW = 0, 1, 2
 
 
@@ -33,7 +35,7 @@ _PROTOS = {
     "orc_scene_destroy": (None, [C.c_void_p]),
     "orc_render_chunk": (C.c_int, [C.c_void_p, _P(RtSettings), _P(RtRenderChunk), C.c_int, C.c_uint64, C.c_uint32,
                                    C.c_int, C.c_void_p, C.c_void_p, _P(OrcCounters)]),
-    "orc_accumulate_chunk": (C.c_int, [C.c_void_p, _P(RtSettings), _P(RtRenderChunk), C.c_uint64, C.c_uint32,
+    "orc_accumulate_chunk": (C.c_int, [C.c_void_p, _P(RtSettings), _P(RtRenderChunk), C.c_int, C.c_uint64, C.c_uint32,
                                        C.c_uint32, C.c_void_p]),
     "orc_render_image_mt": (C.c_int, [C.c_void_p, _P(RtSettings), C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
                                       C.c_uint64, C.c_void_p, C.c_void_p, _P(OrcCounters), _P(C.c_double)]),
@@ -69,6 +71,13 @@ _PROTOS = {
 }
 
 _lib = None
+
+
+def use_lens_mode(scene, mode):
+    """Puts the product scene into lens-sampler `mode` ("reference" / "stratified") and returns the oracle's rng mode for it."""
+    rng_mode, sampler = LENS_MODES[mode]
+    scene.set_option("lens_sampler", sampler)
+    return rng_mode
 
 
 def build():
@@ -127,9 +136,9 @@ class OracleScene:
                                                C.byref(cn)))
         return rgb, rgba, cn
 
-    def accumulate_chunk(self, settings, chunk, seed, sample_first, sample_count):
+    def accumulate_chunk(self, settings, chunk, seed, sample_first, sample_count, rng_mode=ORC_RNG_COUNTER_STRATIFIED):
         acc = np.empty((chunk.height, chunk.width, 3), dtype=np.float32)
-        self._check(self._lib.orc_accumulate_chunk(self._h, C.byref(settings.c), C.byref(chunk), seed, sample_first,
+        self._check(self._lib.orc_accumulate_chunk(self._h, C.byref(settings.c), C.byref(chunk), rng_mode, seed, sample_first,
                                                    sample_count, acc.ctypes.data))
         return acc
 

@@ -12,7 +12,7 @@ import pytest
 
 from raytracer_amd import CameraConfiguration, RenderChunk, RenderSettings, SceneBuilder, decode_image
 from raytracer_amd import _ffi
-from tests.oracle import ORC_RNG_COUNTER, OracleScene
+from tests.oracle import ORC_RNG_COUNTER_STRATIFIED, OracleScene
 
 PIL = pytest.importorskip("PIL.Image")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -121,7 +121,7 @@ def test_textured_dreadnaught_matches_oracle():
     scene, oracle = Scene(b, 0), OracleScene(b)
     st, ch = RenderSettings(w, h, 6, 2), RenderChunk(0, 0, w, h)
     rgb, rgba, cn = scene.render_chunk(st, ch, seed=12345)
-    ref, ref_rgba, rcn = oracle.render_chunk(st, ch, ORC_RNG_COUNTER, 12345, sum_segment=sample_segment())
+    ref, ref_rgba, rcn = oracle.render_chunk(st, ch, ORC_RNG_COUNTER_STRATIFIED, 12345, sum_segment=sample_segment())
     check_image(rgb, ref)
     assert cn.primary == rcn.rays.primary
     assert len(np.unique(rgba.reshape(-1, 4), axis=0)) > 50          # the hull is textured, not one flat colour

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from raytracer_amd import RenderChunk, RenderSettings, RtError, Scene, SceneBuilder, _ffi, camera_new, sample_segment
-from tests.oracle import ORC_RNG_COUNTER, OracleScene
+from tests.oracle import ORC_RNG_COUNTER_STRATIFIED, OracleScene, use_lens_mode
 from tests.test_gpu_parity import check_image, check_primary
 
 pytestmark = pytest.mark.gpu
@@ -21,11 +21,12 @@ def both(b):
     return Scene(b, 0), OracleScene(b)
 
 
-def compare(b, depth=5, spp=2, seed=9, chunk=None, **tol):
+def compare(b, depth=5, spp=2, seed=9, chunk=None, lens_mode="stratified", **tol):
     scene, oracle = both(b)
     st, ch = RenderSettings(W, H, depth, spp), chunk or RenderChunk(0, 0, W, H)
+    rng_mode = use_lens_mode(scene, lens_mode)
     rgb, rgba, cn = scene.render_chunk(st, ch, seed=seed)
-    ref, ref_rgba, rcn = oracle.render_chunk(st, ch, ORC_RNG_COUNTER, seed, sum_segment=sample_segment())
+    ref, ref_rgba, rcn = oracle.render_chunk(st, ch, rng_mode, seed, sum_segment=sample_segment())
     check_image(rgb, ref, **tol)
     assert (cn.primary, cn.samples) == (rcn.rays.primary, rcn.rays.samples)
     return rgb, cn, rcn
@@ -45,7 +46,7 @@ def basic_scene(sky=_ffi.RT_SKY_DAY, light=True, lens_radius=0.0):
 @pytest.mark.parametrize("kinds", ["s", "m", "p", "sm", "sp", "mp", "smp"])
 @pytest.mark.parametrize("xforms", [False, True])
 @pytest.mark.parametrize("rich", [False, True])
-def test_every_instantiation_of_the_render_kernel(kinds, xforms, rich):
+def test_every_instantiation_of_the_render_kernel(kinds, xforms, rich, lens_mode):
     """The render kernel is compiled once per combination of scene traits (kinds of hitable: spheres, mesh instances,
     planes; general transforms; lamp lights / textures beyond colours and checkers) and a scene runs the
     instantiation without the code it does not need; each combination must give the oracle's picture.
@@ -76,7 +77,7 @@ def test_every_instantiation_of_the_render_kernel(kinds, xforms, rich):
     scene, oracle = both(b)
     exact, cover = check_primary(scene, oracle, RenderSettings(W, H, 8, 1), RenderChunk(0, 0, W, H))
     assert exact == 1.0 and cover > 0.1
-    compare(b, depth=6, spp=9)
+    compare(b, depth=6, spp=9, lens_mode=lens_mode)
 
 
 def test_scene_without_lights():
@@ -110,10 +111,10 @@ def test_depth_one_and_maximum_depth():
         scene.render_chunk(RenderSettings(W, H, 32, 1), RenderChunk(0, 0, W, H))
 
 
-@pytest.mark.parametrize("spp", [1, 7, 8, 9, 17])
-def test_ragged_sample_counts(spp):
-    # the last sample segment is partial unless spp is a multiple of rt_sample_segment()
-    compare(basic_scene(lens_radius=0.2), spp=spp)
+@pytest.mark.parametrize("spp", [1, 7, 8, 9, 17, 40])
+def test_ragged_sample_counts(spp, lens_mode):
+    # the last sample segment is partial unless spp is a multiple of rt_sample_segment(); 40 = two groups of 16 + one of 8
+    compare(basic_scene(lens_radius=0.2), spp=spp, lens_mode=lens_mode)
 
 
 @pytest.mark.parametrize("chunk", [(0, 0, 1, 1), (W - 1, H - 1, 1, 1), (5, 0, 1, H), (0, 13, W, 1), (3, 2, 9, 10), (W - 13, H - 11, 13, 11)])
@@ -206,7 +207,7 @@ def test_axis_aligned_rays_on_box_planes():
     assert np.array_equal(e, re) and np.array_equal(tri, rtri) and np.array_equal(t, rt) and np.array_equal(n, rn)
     assert (re >= 0).mean() > 0.1 and (re[:, 32] >= 0).any() and (re[16, :] >= 0).any()     # the zero-component rays hit things
     rgb, _, cn = scene.render_chunk(st, ch, seed=2)
-    ref, _, rcn = oracle.render_chunk(st, ch, ORC_RNG_COUNTER, 2, sum_segment=sample_segment())
+    ref, _, rcn = oracle.render_chunk(st, ch, ORC_RNG_COUNTER_STRATIFIED, 2, sum_segment=sample_segment())
     assert np.abs(rgb - ref).max() < 2e-5 and cn.rays == rcn.rays.primary + rcn.rays.secondary + rcn.rays.shadow
 
 
@@ -218,3 +219,69 @@ def test_point_cloud_large_tlas():
     assert scene.info().tlas_depth >= 17
     exact, _ = check_primary(scene, oracle, RenderSettings(W, H, 4, 1), RenderChunk(0, 0, W, H))
     assert exact > 0.999
+
+
+def test_traversal_stack_overflow_is_an_error_not_a_wrong_image():
+    """The per-lane traversal stack is sized from the trees at scene creation; if it is ever too small the kernel must not
+    drop the subtree silently: a sticky per-scene error word turns the call (and every later one) into RT_E_DEPTH.
+    Forced here by running the kernels with a 1-entry stack (RT_OPT_DEBUG_STACK_ENTRIES)."""
+    import torch
+    from raytracer_amd import CameraConfiguration
+    b = SceneBuilder.sample("Random Spheres", CameraConfiguration(W, H, lens_radius=0.1))
+    scene, _ = both(b)
+    st, ch = RenderSettings(W, H, 4, 2), RenderChunk(0, 0, W, H)
+    good, _, _ = scene.render_chunk(st, ch, seed=1)
+    scene.set_option("debug_stack_entries", 1)
+    with pytest.raises(RtError, match="traversal stack") as e:
+        scene.render_chunk(st, ch, seed=1)
+    assert e.value.code == _ffi.RT_E_DEPTH
+    with pytest.raises(RtError, match="traversal stack"):          # sticky: the blocking entry points ...
+        scene.primary_hits(st, ch)
+    out = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda:0")
+    with pytest.raises(RtError, match="traversal stack"):          # ... and the enqueue-only ones refuse further work
+        scene.render_chunk_device(st, ch, 1, out.data_ptr(), None, W, 0, 0, None, torch.cuda.current_stream().cuda_stream)
+    scene.set_option("debug_stack_entries", 0)                     # as built again; re-arms the error word
+    again, _, _ = scene.render_chunk(st, ch, seed=1)
+    assert np.array_equal(again, good)
+    # an overflow inside an enqueued launch surfaces at the next call on the scene
+    scene.set_option("debug_stack_entries", 1)
+    scene.render_chunk_device(st, ch, 1, out.data_ptr(), None, W, 0, 0, None, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    with pytest.raises(RtError, match="traversal stack"):
+        scene.render_chunk_device(st, ch, 1, out.data_ptr(), None, W, 0, 0, None, torch.cuda.current_stream().cuda_stream)
+    scene.set_option("debug_stack_entries", 0)
+
+
+def test_strip_height_must_hold_whole_ray_tiles():
+    """rt_render_strips_device maps an 8x8 ray tile through the strip interleave by its first row, so a strip height that is
+    not a multiple of 8 would scatter rows 4..7 of a tile to wrong image rows: refused (RT_E_INVALID), 16 works."""
+    import torch
+    from raytracer_amd import strip_rows
+    scene, _ = both(basic_scene())
+    st = RenderSettings(W, H, 3, 2)
+    whole, _, _ = scene.render_chunk(st, RenderChunk(0, 0, W, H), seed=3)
+    stream = torch.cuda.current_stream().cuda_stream
+    buf = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda:0")
+    for bad in (4, 12, 7):
+        with pytest.raises(RtError, match="multiple of 8") as e:
+            scene.render_strips_device(st, bad, 0, 2, 3, buf.data_ptr(), None, None, stream)
+        assert e.value.code == _ffi.RT_E_INVALID
+    frame = np.zeros_like(whole)
+    for r in range(2):
+        rows = strip_rows(H, 16, r, 2)
+        scene.render_strips_device(st, 16, r, 2, 3, buf.data_ptr(), None, None, stream)
+        torch.cuda.synchronize()
+        idx = [y for top in range(r * 16, H, 32) for y in range(top, min(top + 16, H))]
+        assert len(idx) == rows
+        frame[idx] = buf[:rows].cpu().numpy()
+    assert np.array_equal(frame, whole)
+
+
+def test_scene_options_are_validated():
+    scene, _ = both(basic_scene())
+    for name, bad in (("lens_sampler", 2), ("fine_split", 3), ("round_units", 3), ("lens_coc_px", -1.0), ("debug_stack_entries", -5)):
+        with pytest.raises(RtError) as e:
+            scene.set_option(name, bad)
+        assert e.value.code == _ffi.RT_E_INVALID
+    with pytest.raises(RtError, match="unknown option"):
+        scene._check(scene._lib.rt_scene_set_option(scene._h, 77, 0.0))

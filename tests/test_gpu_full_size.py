@@ -10,7 +10,7 @@ import pytest
 
 from raytracer_amd import (CameraConfiguration, RenderChunk, RenderSettings, Scene, SceneBuilder, create_render_chunks,
                            resolve_device, sample_segment, strip_rows)
-from tests.oracle import ORC_RNG_COUNTER, OracleScene
+from tests.oracle import ORC_RNG_COUNTER_STRATIFIED, OracleScene, use_lens_mode
 from tests.test_gpu_parity import PRIMARY_RTOL, check_image
 
 pytestmark = pytest.mark.gpu
@@ -109,16 +109,25 @@ def test_sample_ranges_add_up(frame):
     assert torch.equal(out, s["rgb"])
 
 
-def test_sampled_chunks_match_the_oracle_at_full_spp(frame):
+def test_sampled_chunks_match_the_oracle_at_full_spp(frame, lens_mode):
+    """24x24 chunks sampled from the frame, at the config's full sample count, under both lens samplers (the frame of the
+    fixture is the default, stratified one; under the reference's sampler the chunks are rendered on their own)."""
     s = frame
     oracle = OracleScene(s["b"])
     rng = np.random.default_rng(5)
     host = s["rgb"].cpu().numpy()
-    for _ in range(4):
-        l, t = int(rng.integers(0, s["w"] - 24)), int(rng.integers(0, s["h"] - 24))
-        ch = RenderChunk(l, t, 24, 24)
-        ref, _, _ = oracle.render_chunk(s["st"], ch, ORC_RNG_COUNTER, 12345, sum_segment=sample_segment())
-        check_image(host[t:t + 24, l:l + 24], ref, outlier_frac=5e-3)
+    rng_mode = use_lens_mode(s["scene"], lens_mode)
+    try:
+        for _ in range(4):
+            l, t = int(rng.integers(0, s["w"] - 24)), int(rng.integers(0, s["h"] - 24))
+            ch = RenderChunk(l, t, 24, 24)
+            ref, _, _ = oracle.render_chunk(s["st"], ch, rng_mode, 12345, sum_segment=sample_segment())
+            got, _, _ = s["scene"].render_chunk(s["st"], ch, seed=12345)
+            if lens_mode == "stratified":
+                assert np.array_equal(got, host[t:t + 24, l:l + 24])       # the chunk call returns the frame's pixels
+            check_image(got, ref, outlier_frac=5e-3)
+    finally:
+        use_lens_mode(s["scene"], "stratified")
 
 
 def test_sampled_primary_hits_match_the_oracle(frame):
@@ -141,7 +150,7 @@ def test_sampled_primary_hits_match_the_oracle(frame):
     assert min(exact) == 1.0, exact          # in fact bit-identical
 
 
-def test_dootdoot_chunk_at_4096_spp():
+def test_dootdoot_chunk_at_4096_spp(lens_mode):
     """BASELINE configs[4] at its own sample count, on one chunk the oracle can afford: 512 segments of 8 samples,
     accumulated as the 8 ranks of the spp split would (8 x 512 samples) and as one call."""
     import torch
@@ -150,6 +159,7 @@ def test_dootdoot_chunk_at_4096_spp():
     b = SceneBuilder.sample("Doot Doot", CameraConfiguration(w, h, lens_radius=0.1), params=DOOT)
     scene, oracle = Scene(b, 0), OracleScene(b)
     st, ch = RenderSettings(w, h, 8, spp), RenderChunk(1912, 1076, 16, 16)
+    rng_mode = use_lens_mode(scene, lens_mode)
     one, _, cn = scene.render_chunk(st, ch, seed=12345)
     stream = torch.cuda.current_stream().cuda_stream
     acc = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda:0")
@@ -162,7 +172,7 @@ def test_dootdoot_chunk_at_4096_spp():
     split = out.view(h, w, 3)[ch.top:ch.top + 16, ch.left:ch.left + 16].cpu().numpy()
     assert np.array_equal(split, one)
     assert cn.samples == 16 * 16 * spp == cn.primary
-    ref, _, rcn = oracle.render_chunk(st, ch, ORC_RNG_COUNTER, 12345, sum_segment=sample_segment())
+    ref, _, rcn = oracle.render_chunk(st, ch, rng_mode, 12345, sum_segment=sample_segment())
     check_image(one, ref, outlier_frac=5e-3)
     assert rcn.rays.primary == cn.primary and abs(rcn.rays.shadow - cn.shadow) <= 2e-3 * rcn.rays.shadow
     scene.close()

@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 
 from raytracer_amd import RenderChunk, RenderSettings, Scene, SceneBuilder, _ffi, camera_new, sample_segment
-from tests.oracle import ORC_RNG_COUNTER, OracleScene
+from tests.oracle import ORC_RNG_COUNTER_STRATIFIED, OracleScene
 from tests.test_gpu_parity import check_image
 
 pytestmark = pytest.mark.gpu
@@ -91,7 +91,7 @@ def test_random_scene_matches_oracle(seed):
     # the image: recursion, shadows through glass, every texture kind
     st = RenderSettings(W, H, 5, 3)
     rgb, _, cn = scene.render_chunk(st, whole, seed=seed)
-    ref, _, rcn = oracle.render_chunk(st, whole, ORC_RNG_COUNTER, seed, sum_segment=sample_segment())
+    ref, _, rcn = oracle.render_chunk(st, whole, ORC_RNG_COUNTER_STRATIFIED, seed, sum_segment=sample_segment())
     # a decision flip of one secondary ray (last-ulp libm difference) changes a whole pixel: allowed as an
     # outlier, but on an 80x48 image one such pixel moves the mean by 1e-4, hence the looser mean bound
     check_image(rgb, ref, outlier_frac=5e-3, mean_atol=3e-4)

@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np  # noqa: E402
 
 from raytracer_amd import CameraConfiguration, RenderSettings, SceneBuilder  # noqa: E402
-from tests.oracle import ORC_RNG_COUNTER, OracleScene, lib  # noqa: E402
+from tests.oracle import ORC_RNG_COUNTER_STRATIFIED, OracleScene, lib  # noqa: E402
 
 
 class OrcMismatch(C.Structure):
@@ -51,7 +51,7 @@ def main():
     st = RenderSettings(a.width, a.height, a.depth, a.spp)
     grid = (32, 32)
     cn, ms = oracle.render_chunks_mt(st, grid, 5, a.stride, (grid[0] * grid[1] - 6) // a.stride, os.cpu_count() or 1,
-                                     rng_mode=ORC_RNG_COUNTER, seed=12345, stats=True)
+                                     rng_mode=ORC_RNG_COUNTER_STRATIFIED, seed=12345, stats=True)
     rays = cn.rays.primary + cn.rays.secondary + cn.rays.shadow
     buf = (OrcMismatch * 100000)()
     n = L.orc_mismatch_read(buf, 100000)
