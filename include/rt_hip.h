@@ -292,6 +292,23 @@ int rt_render_chunk_device(RtScene* scene, const RtSettings* settings,
                            uint32_t pitch_pixels, uint32_t out_x, uint32_t out_y,
                            void* counters_dev, void* stream);
 
+/* rt_render_chunk_device for callers that cannot allocate.  NO counterpart in the reference: it exists for
+ * code under HIP graph capture, tight serving loops and harnesses that forbid hipMalloc.  Same arguments, same
+ * pixels (bit for bit) as rt_render_chunk_device, but the call allocates nothing (no hipMalloc / hipFree, no
+ * events): its scratch - segment sums, chunk accumulator, block counters, tile order - is carved out of ONE
+ * static array of 32 MiB in device memory that every GPU the library runs on holds until the process ends.
+ * Limits: a chunk of at most rt_noalloc_max_pixels() pixels after padding to whole 8x8 tiles (about 1.34 M,
+ * e.g. 1024 x 1024; RT_E_LIMIT beyond); chunks above a sixteenth of that run with fewer sample segments per
+ * launch (slower, same bits).  Every call on a GPU shares that GPU's array: calls that overlap on one GPU
+ * (different streams, or different scenes on one device) race - keep them on one stream.  The scene's
+ * rt_scene_profile_* hook does not see these launches. */
+int rt_render_chunk_device_noalloc(RtScene* scene, const RtSettings* settings,
+                                   const RtRenderChunk* chunk, uint64_t seed,
+                                   void* rgb_dev, void* rgba_dev,
+                                   uint32_t pitch_pixels, uint32_t out_x, uint32_t out_y,
+                                   void* counters_dev, void* stream);
+uint64_t rt_noalloc_max_pixels(void);
+
 /* Tile-partitioned rendering for one of N GPUs (partitioning 1).
  * Replaces the shared chunk queue of the reference's worker threads
  * (src/render.rs:186-224, 63-78): the frame is cut into horizontal strips of

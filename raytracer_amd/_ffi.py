@@ -159,6 +159,9 @@ HIP_PROTOTYPES = {
                                   _P(RtRayCounters)]),
     "rt_render_chunk_device": (C.c_int, [C.c_void_p, _P(RtSettings), _P(RtRenderChunk), C.c_uint64, C.c_void_p,
                                          C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "rt_render_chunk_device_noalloc": (C.c_int, [C.c_void_p, _P(RtSettings), _P(RtRenderChunk), C.c_uint64, C.c_void_p,
+                                         C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "rt_noalloc_max_pixels": (C.c_uint64, []),
     "rt_render_strips_device": (C.c_int, [C.c_void_p, _P(RtSettings), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rt_sample_segment": (C.c_uint32, []),

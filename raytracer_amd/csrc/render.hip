@@ -1343,20 +1343,50 @@ int set_error(int code, const std::string& msg) { g_error = msg; return code; }
 
 struct DeviceBuffer {
     void* p = nullptr; size_t bytes = 0;
+    bool fixed = false;      // a slice of the allocation-free entry point's static scratch: never grown, never freed
     int ensure(size_t n) {
         if (n <= bytes) return RT_OK;
+        if (fixed) return set_error(RT_E_LIMIT, "rt_render_chunk_device_noalloc: the call needs more scratch than the library's static array holds");
         if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
         HIP_TRY(hipMalloc(&p, n));
         bytes = n; return RT_OK;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+    void release() { if (p && !fixed) (void)hipFree(p); p = nullptr; bytes = 0; }
 };
 
 }  // namespace
 
+// ---- scratch of the allocation-free entry point (rt_render_chunk_device_noalloc) ---------------------------------
+// One static array in device memory per GPU the library runs on (held until the process ends): the segment sums, the
+// chunk accumulator, the block counters and the tile order of ONE call are carved out of it.  `scratch` is a host-side
+// stand-in, not a device address: host code only ever uses the per-device address hipGetSymbolAddress returned
+// (scratch_address(), taken once per device in rt_scene_create with that device current).
+#define RT_NOALLOC_SCRATCH_BYTES (32u << 20)
+static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_SCRATCH_BYTES];
+
+#define RT_MAX_DEVICES 64
+static std::mutex g_scratch_lock;
+static unsigned char* g_scratch_ptr[RT_MAX_DEVICES] = {};      // [device]: that GPU's copy of the array
+static std::mutex g_scratch_call_lock[RT_MAX_DEVICES];          // serialises the ENQUEUEING of no-alloc calls per device
+
+// Address of `device`'s copy of the scratch array; the first call per device (with that device current) asks HIP for it.
+static int scratch_address(int device, unsigned char** out) {
+    if (device < 0 || device >= RT_MAX_DEVICES) return set_error(RT_E_LIMIT, "device index beyond RT_MAX_DEVICES");
+    std::lock_guard<std::mutex> g(g_scratch_lock);
+    if (!g_scratch_ptr[device]) {
+        void* ptr = nullptr;
+        hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !ptr) return set_error(RT_E_HIP, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e));
+        g_scratch_ptr[device] = (unsigned char*)ptr;
+    }
+    *out = g_scratch_ptr[device];
+    return RT_OK;
+}
+
 // Everything one in-flight render call writes besides the caller's outputs.
 struct Workspace {
     hipStream_t stream = nullptr;    // own stream (host-pointer entry points only)
+    bool no_alloc = false;           // buffers are fixed slices of the static scratch: nothing may be allocated on their behalf
     DeviceBuffer partial, accum, out_rgb, out_rgba, ctrl, prim, order;
     int init(bool with_stream) {
         if (with_stream) HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
@@ -1391,6 +1421,7 @@ struct RtScene {
     std::vector<uint32_t> tlas_order;
     std::vector<std::vector<uint32_t>> blas_order;
     std::vector<void*> allocations;
+    unsigned char* scratch_ptr = nullptr;   // this device's copy of the static scratch array (rt_render_chunk_device_noalloc)
     // Device-pointer entry points run on the CALLER's stream and share this workspace:
     // `lock` serialises their enqueueing, the caller keeps them on one stream.
     std::mutex lock;
@@ -1505,10 +1536,12 @@ int enqueue_accumulate(RtScene* scene, Workspace& ws, const RtSettings* st, cons
     { std::lock_guard<std::mutex> og(scene->opt_lock); opt = scene->opt; }
     bool fine = coarse_blocks < (uint64_t)scene->grid_blocks * (RT_BLOCK / 64) && scene->host_calls_in_flight.load() <= 1;
     if (opt.fine_split >= 0) fine = opt.fine_split != 0;                                 // RT_OPT_FINE_SPLIT (experiments / tests): force either split
+    if (fine && ws.partial.fixed && ws.partial.bytes < (uint64_t)pix_slots * 12ull * RT_SAMPLE_SEGMENT) fine = false;      // (same bits either way)
     const uint32_t unit_len = fine ? 1u : RT_SAMPLE_SEGMENT;
     // segments per launch: keep the scratch below ~2 GiB (a 4K frame then still runs 16 units per launch)
     const uint32_t units_per_seg = RT_SAMPLE_SEGMENT / unit_len;
-    uint32_t batch = (uint32_t)((1ull << 31) / ((uint64_t)pix_slots * 12ull * units_per_seg));
+    const uint64_t partial_cap = ws.partial.fixed ? ws.partial.bytes : (1ull << 31);      // (the static scratch of the no-alloc entry point is what it is)
+    uint32_t batch = (uint32_t)(partial_cap / ((uint64_t)pix_slots * 12ull * units_per_seg));
     if (batch == 0) batch = 1;
     if (batch > nseg) batch = nseg;
     if (batch >= 16) batch &= ~15u;           // (whole groups of units that share their rounds, see round_units_shift
@@ -1566,9 +1599,10 @@ int enqueue_accumulate(RtScene* scene, Workspace& ws, const RtSettings* st, cons
         HIP_TRY(hipMemsetAsync(P.block_counter, 0, RT_QUEUES * 64, stream));
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
         bool profiling;
-        { std::lock_guard<std::mutex> pg(scene->profile_lock); profiling = scene->profiling; }
+        { std::lock_guard<std::mutex> pg(scene->profile_lock); profiling = scene->profiling && !ws.no_alloc; }      // (events are created per launch)
         if (profiling) { HIP_TRY(hipEventCreate(&ev0)); HIP_TRY(hipEventCreate(&ev1)); HIP_TRY(hipEventRecord(ev0, stream)); }
 #ifdef RT_PHASE_STATS
+        if (ws.no_alloc) return set_error(RT_E_INVALID, "the phase-statistics build allocates: not with the no-alloc entry point");
         static unsigned long long* phase_dev = nullptr;
         if (!phase_dev) HIP_TRY(hipMalloc((void**)&phase_dev, PH_COUNT * 16));
         HIP_TRY(hipMemsetAsync(phase_dev, 0, PH_COUNT * 16, stream));
@@ -1651,6 +1685,7 @@ RtScene* rt_scene_create(const RtSceneDesc* desc, int device) {
     if (hipSetDevice(device) != hipSuccess) { set_error(RT_E_HIP, "hipSetDevice failed"); return fail(); }
     s->view = flat.view; s->info = flat.info;
     s->tlas_order = std::move(flat.tlas_order); s->blas_order = std::move(flat.blas_order);
+    if (scratch_address(device, &s->scratch_ptr)) return fail();      // (this device is current: its copy of the array)
     if (upload(s, flat.nodes, &s->view.nodes) || upload(s, flat.entities, &s->view.entities) || upload(s, flat.xforms, &s->view.xforms) ||
         upload(s, flat.meshes, &s->view.meshes) || upload(s, flat.tri_hot, &s->view.tri_hot) || upload(s, flat.tri_cold, &s->view.tri_cold) ||
         upload(s, flat.tri_rank, &s->view.tri_rank) || upload(s, flat.planes, &s->view.planes) || upload(s, flat.materials, &s->view.materials) ||
@@ -1742,6 +1777,36 @@ int rt_render_chunk_device(RtScene* scene, const RtSettings* st, const RtRenderC
     if (rc) return rc;
     std::lock_guard<std::mutex> g(scene->lock);
     return render_chunk_device_on(scene, scene->shared, st, ch, seed, rgb_dev, rgba_dev, pitch_pixels, out_x, out_y, counters_dev, (hipStream_t)stream);
+}
+
+uint64_t rt_noalloc_max_pixels(void) {
+    // control words + tile order (8 B per 64 pixels) + accumulator (12 B) + the segment sums of at least one unit (12 B)
+    return ((uint64_t)RT_NOALLOC_SCRATCH_BYTES - 4096u - 1024u) / (12u + 12u + 1u) / 64u * 64u;
+}
+
+int rt_render_chunk_device_noalloc(RtScene* scene, const RtSettings* st, const RtRenderChunk* ch, uint64_t seed, void* rgb_dev, void* rgba_dev,
+                                   uint32_t pitch_pixels, uint32_t out_x, uint32_t out_y, void* counters_dev, void* stream) {
+    int rc = validate_call(scene, st, ch);
+    if (rc) return rc;
+    const uint64_t pix_slots = (((uint64_t)ch->width + 7) / 8) * (((uint64_t)ch->height + 7) / 8) * 64;      // whole 8x8 ray tiles
+    if (pix_slots > rt_noalloc_max_pixels())
+        return set_error(RT_E_LIMIT, "rt_render_chunk_device_noalloc: chunk of " + std::to_string(pix_slots) + " tile-padded pixels exceeds the static scratch (" +
+                                     std::to_string(rt_noalloc_max_pixels()) + " pixels, rt_noalloc_max_pixels()); render it in smaller chunks");
+    if (!scene->scratch_ptr) return set_error(RT_E_HIP, "no scratch address for this scene's device");
+    // Carve this call's workspace out of the device's static array (all offsets multiples of 256 bytes).  Every call on a GPU
+    // shares the array and finds the previous call's contents in it: the block counters are cleared per launch
+    // (enqueue_accumulate), everything else is written before it is read.
+    auto up = [](size_t n) { return (n + 255) & ~(size_t)255; };
+    unsigned char* base = scene->scratch_ptr;
+    size_t at = 0;
+    Workspace ws; ws.no_alloc = true;
+    auto carve = [&](DeviceBuffer& b, size_t n) { b.p = base + at; b.bytes = n; b.fixed = true; at += up(n); };
+    carve(ws.ctrl, 1024 + RT_QUEUES * 64);
+    carve(ws.order, (size_t)(pix_slots / 64) * 8 + 16);
+    carve(ws.accum, (size_t)ch->width * ch->height * 12);
+    carve(ws.partial, RT_NOALLOC_SCRATCH_BYTES - at);           // the rest: as many units per launch as fit
+    std::lock_guard<std::mutex> g(g_scratch_call_lock[scene->device]);
+    return render_chunk_device_on(scene, ws, st, ch, seed, rgb_dev, rgba_dev, pitch_pixels, out_x, out_y, counters_dev, (hipStream_t)stream);
 }
 
 int rt_render_chunk(RtScene* scene, const RtSettings* st, const RtRenderChunk* ch, uint64_t seed, float* rgb_out, uint8_t* rgba_out,

@@ -303,6 +303,12 @@ class Scene:
         self._check(self._lib.rt_render_chunk_device(self._h, C.byref(settings.c), C.byref(chunk), seed, rgb_ptr,
                                                      rgba_ptr, pitch_pixels, out_x, out_y, counters_ptr, stream))
 
+    def render_chunk_device_noalloc(self, settings, chunk, seed, rgb_ptr, rgba_ptr, pitch_pixels, out_x, out_y,
+                                    counters_ptr=None, stream=None):
+        """rt_render_chunk_device_noalloc: same pixels, scratch from the library's static device array, nothing allocated."""
+        self._check(self._lib.rt_render_chunk_device_noalloc(self._h, C.byref(settings.c), C.byref(chunk), seed, rgb_ptr,
+                                                             rgba_ptr, pitch_pixels, out_x, out_y, counters_ptr, stream))
+
     def render_strips_device(self, settings, strip_height, strip_first, strip_period, seed, rgb_ptr, rgba_ptr,
                              counters_ptr=None, stream=None):
         """Every strip_period-th strip of the frame, one launch, packed output rows."""
