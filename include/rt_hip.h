@@ -236,6 +236,18 @@ RtScene* rt_scene_create(const RtSceneDesc* desc, int device);
 #define RT_DEVICE_HOST_ONLY (-1)
 void     rt_scene_destroy(RtScene* scene);
 
+/* Animated scenes: new entity transforms for an existing scene (the reference rebuilds everything per
+ * frame: Scene::build_bvh, implementation.rs:377-383, e.g. raytracer-samples/src/scene_interceptor_spin.rs:34-40).
+ * `translations` / `rotations` replace the arrays given to rt_scene_create and must have the same sizes; every entity keeps
+ * its ranges in them.  Entity boxes (Entity::calculate_origin_aabb, implementation.rs:258-283) and the TLAS boxes above
+ * them are recomputed ON THE DEVICE (refit: the tree keeps the topology, leaves and visit ranks it was built with, BLASes
+ * are untouched); the host only evaluates sin / cos of the rotation angles, with the libm the reference calls per ray.
+ * Hits are those of a fresh rt_scene_create of the moved scene, except which of two entities wins an EXACT tie in t (the
+ * visit ranks are those of the original tree).  Enqueued on `stream`, then waits for it (the host needs the new root box).
+ * No render call on this scene may be in flight. */
+int rt_scene_update_transforms(RtScene* scene, const RtV3* translations, uint64_t translation_count,
+                               const RtRotation* rotations, uint64_t rotation_count, void* stream);
+
 /* Switches of the sampler and of the launch schedule of one scene (no reference counterpart except
  * RT_OPT_LENS_SAMPLER 0).  Takes effect for calls that start afterwards.  Defaults can be preset through the
  * environment, read once in rt_scene_create: RT_LENS_STRATIFY, RT_FINE_SPLIT, RT_ROUND_UNITS, RT_LENS_COC. */

@@ -1321,6 +1321,90 @@ primary_kernel(const DevSceneView S, const RenderParams P, float* t_out, float* 
 }
 
 // ===========================================================================
+// refit of the TLAS after a change of the entity transforms (rt_scene_update_transforms)
+// ===========================================================================
+// Entity::calculate_origin_aabb (implementation.rs:258-283) for every entity, with the arithmetic of the host build
+// (scene_build.cpp: rotate() = types.rs:200 with cos / sin evaluated by the host libm and handed over in the transform
+// records), so the boxes are bit for bit those a fresh rt_scene_create would compute.  Also refreshes the entity's inline
+// first translation.  ent_box: 8 floats per TLAS position (lo.xyz, -, hi.xyz, -).
+__global__ void refit_entities_kernel(DevEntity* entities, const Word4* xforms, const DevMesh* meshes, float* ent_box, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Word4* ew = entities[i].w;
+    const Word4 e0 = ldw(ew), e1 = ldw(ew + 1);
+    const uint32_t kind = e1.u[0] & 0xff, n_trans = (e1.u[0] >> 8) & 0xff, n_rot = (e1.u[0] >> 16) & 0xff;
+    const Word4* x = xforms + e1.u[2];
+    const float inf = __builtin_inff();
+    F3 lo, hi;
+    bool infinite = false;
+    if (kind == RT_HITABLE_SPHERE) { const float r = e0.f[3]; lo = f3(0.0f - r, 0.0f - r, 0.0f - r); hi = f3(0.0f + r, 0.0f + r, 0.0f + r); }      // sphere.rs:55-58
+    else if (kind == RT_HITABLE_PLANE) { lo = f3(-inf, -inf, -inf); hi = f3(inf, inf, inf); infinite = true; }                                  // plane.rs:92-95
+    else { const Word4* mw = meshes[e1.u[1]].w; const Word4 m1 = ldw(mw + 1), m2 = ldw(mw + 2); lo = f3(m1.f[0], m1.f[1], m1.f[2]); hi = f3(m1.f[3], m2.f[0], m2.f[1]); }
+    // AABB::corners, implementation.rs:120-131
+    F3 c[8] = {lo, f3(lo.x, lo.y, hi.z), f3(lo.x, hi.y, lo.z), f3(hi.x, lo.y, lo.z), hi, f3(hi.x, hi.y, lo.z), f3(hi.x, lo.y, hi.z), f3(lo.x, hi.y, hi.z)};
+    if (!infinite)
+        for (uint32_t k = n_rot; k-- > 0;) {
+            const Word4 a = ldw(x + n_trans + 2 * k), b = ldw(x + n_trans + 2 * k + 1);
+#pragma unroll
+            for (int q = 0; q < 8; q++) c[q] = rotate_cs(c[q], w3(a), b.f[1], b.f[2]);      // + theta
+        }
+    for (uint32_t k = 0; k < n_trans; k++) {
+        const F3 t = w3(ldw(x + k));
+#pragma unroll
+        for (int q = 0; q < 8; q++) c[q] = c[q] + t;
+    }
+    F3 bl = c[0], bh = c[0];
+#pragma unroll
+    for (int q = 1; q < 8; q++) {
+        bl = f3(fminf(bl.x, c[q].x), fminf(bl.y, c[q].y), fminf(bl.z, c[q].z));
+        bh = f3(fmaxf(bh.x, c[q].x), fmaxf(bh.y, c[q].y), fmaxf(bh.z, c[q].z));
+    }
+    float* o = ent_box + (size_t)i * 8;
+    o[0] = bl.x; o[1] = bl.y; o[2] = bl.z; o[3] = 0.0f; o[4] = bh.x; o[5] = bh.y; o[6] = bh.z; o[7] = 0.0f;
+    if (n_trans > 0) { const Word4 t0 = ldw(x); float* w0 = ew[0].f; w0[0] = t0.f[0]; w0[1] = t0.f[1]; w0[2] = t0.f[2]; }      // (w0.w keeps the radius)
+}
+
+// Box of one child of a TLAS record: the union of a range of entity boxes (count > 0) or of the two boxes of the child's own
+// record (count == 0, written by the previous, deeper level).  Unions are exact (min / max), like the host build's.
+__device__ __forceinline__ void refit_child_box(const DevNode* nodes, const float* ent_box, uint32_t first, uint32_t count, uint32_t child, F3& lo, F3& hi) {
+    if (count > 0) {
+        const float* b = ent_box + (size_t)first * 8;
+        lo = f3(b[0], b[1], b[2]); hi = lo;                                                   // bvh.rs:109-116 folds [min, max] of each object in order
+        for (uint32_t k = 0; k < count; k++) {
+            const float* q = ent_box + (size_t)(first + k) * 8;
+            lo = f3(fminf(fminf(lo.x, q[0]), q[4]), fminf(fminf(lo.y, q[1]), q[5]), fminf(fminf(lo.z, q[2]), q[6]));
+            hi = f3(fmaxf(fmaxf(hi.x, q[0]), q[4]), fmaxf(fmaxf(hi.y, q[1]), q[5]), fmaxf(fmaxf(hi.z, q[2]), q[6]));
+        }
+    } else {
+        const Word4* n = nodes[child].w;
+        const Word4 a = ldw(n), b = ldw(n + 1), c = ldw(n + 2);
+        lo = f3(fminf(a.f[0], a.f[1]), fminf(a.f[2], a.f[3]), fminf(b.f[0], b.f[1]));
+        hi = f3(fmaxf(b.f[2], b.f[3]), fmaxf(c.f[0], c.f[1]), fmaxf(c.f[2], c.f[3]));
+    }
+}
+
+__global__ void refit_level_kernel(DevNode* nodes, const RefitRec* recs, uint32_t first, uint32_t count, const float* ent_box) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const RefitRec r = recs[first + i];
+    F3 ll, lh, rl, rh;
+    refit_child_box(nodes, ent_box, r.l_first, r.l_count, r.l_child, ll, lh);
+    refit_child_box(nodes, ent_box, r.r_first, r.r_count, r.r_child, rl, rh);
+    float* w = nodes[r.node].w[0].f;      // layout: device_scene.h
+    w[0] = ll.x; w[1] = rl.x; w[2] = ll.y; w[3] = rl.y;
+    w[4] = ll.z; w[5] = rl.z; w[6] = lh.x; w[7] = rh.x;
+    w[8] = lh.y; w[9] = rh.y; w[10] = lh.z; w[11] = rh.z;
+}
+
+// The TLAS root box (DevSceneView::tlas_min / tlas_max): the root record's two boxes, or - a scene of one leaf - its entities.
+__global__ void refit_root_kernel(const DevNode* nodes, uint32_t root_ref, uint32_t n_entities, const float* ent_box, float* root_box) {
+    F3 lo, hi;
+    if (root_ref & RT_REF_LEAF_BIT) refit_child_box(nodes, ent_box, 0u, n_entities, 0u, lo, hi);
+    else refit_child_box(nodes, ent_box, 0u, 0u, root_ref, lo, hi);
+    root_box[0] = lo.x; root_box[1] = lo.y; root_box[2] = lo.z; root_box[3] = hi.x; root_box[4] = hi.y; root_box[5] = hi.z;
+}
+
+// ===========================================================================
 // host side
 // ===========================================================================
 thread_local std::string g_error;
@@ -1422,6 +1506,16 @@ struct RtScene {
     std::vector<std::vector<uint32_t>> blas_order;
     std::vector<void*> allocations;
     unsigned char* scratch_ptr = nullptr;   // this device's copy of the static scratch array (rt_render_chunk_device_noalloc)
+    // rt_scene_update_transforms: what the host needs to re-derive the transform records, and the device-side refit tables
+    RtCamera camera{};
+    std::vector<RtEntity> desc_entities;
+    std::vector<uint32_t> tlas_perm;
+    uint64_t n_translations = 0, n_rotations = 0;
+    std::vector<Word4> xforms_host;
+    size_t xforms_words = 0;
+    std::vector<uint32_t> refit_level_start;
+    const RefitRec* refit_dev = nullptr;
+    float* ent_box_dev = nullptr;           // 8 floats per entity + 8 for the root box
     // Device-pointer entry points run on the CALLER's stream and share this workspace:
     // `lock` serialises their enqueueing, the caller keeps them on one stream.
     std::mutex lock;
@@ -1686,6 +1780,19 @@ RtScene* rt_scene_create(const RtSceneDesc* desc, int device) {
     s->view = flat.view; s->info = flat.info;
     s->tlas_order = std::move(flat.tlas_order); s->blas_order = std::move(flat.blas_order);
     if (scratch_address(device, &s->scratch_ptr)) return fail();      // (this device is current: its copy of the array)
+    s->camera = desc->camera;
+    s->desc_entities.assign(desc->entities, desc->entities + desc->entity_count);
+    s->tlas_perm = std::move(flat.tlas_perm);
+    s->n_translations = desc->translation_count; s->n_rotations = desc->rotation_count;
+    s->xforms_words = flat.xforms.size();
+    s->refit_level_start = std::move(flat.refit_level_start);
+    if (flat.refit.empty()) flat.refit.emplace_back();
+    if (upload(s, flat.refit, &s->refit_dev)) return fail();
+    {
+        void* p = nullptr;
+        if (hipMalloc(&p, ((size_t)desc->entity_count + 1) * 8 * sizeof(float)) != hipSuccess) { set_error(RT_E_HIP, "hipMalloc (entity boxes) failed"); return fail(); }
+        s->allocations.push_back(p); s->ent_box_dev = (float*)p;
+    }
     if (upload(s, flat.nodes, &s->view.nodes) || upload(s, flat.entities, &s->view.entities) || upload(s, flat.xforms, &s->view.xforms) ||
         upload(s, flat.meshes, &s->view.meshes) || upload(s, flat.tri_hot, &s->view.tri_hot) || upload(s, flat.tri_cold, &s->view.tri_cold) ||
         upload(s, flat.tri_rank, &s->view.tri_rank) || upload(s, flat.planes, &s->view.planes) || upload(s, flat.materials, &s->view.materials) ||
@@ -1829,6 +1936,46 @@ int rt_render_chunk(RtScene* scene, const RtSettings* st, const RtRenderChunk* c
     HIP_TRY(hipStreamSynchronize(ws.stream));
     if ((rc = check_device_error(scene))) return rc;
     if (counters) { counters->primary += c.primary; counters->secondary += c.secondary; counters->shadow += c.shadow; counters->samples += c.samples; }
+    return RT_OK;
+}
+
+int rt_scene_update_transforms(RtScene* scene, const RtV3* translations, uint64_t translation_count, const RtRotation* rotations,
+                               uint64_t rotation_count, void* stream) {
+    if (!scene) return set_error(RT_E_INVALID, "null scene");
+    if (scene->device == RT_DEVICE_HOST_ONLY) return set_error(RT_E_NO_DEVICE, "scene was created host-only");
+    if (translation_count != scene->n_translations || rotation_count != scene->n_rotations)
+        return set_error(RT_E_INVALID, "rt_scene_update_transforms: the arrays must have the sizes given to rt_scene_create (entities keep their ranges)");
+    if ((translation_count && !translations) || (rotation_count && !rotations)) return set_error(RT_E_INVALID, "null transform array");
+    std::lock_guard<std::mutex> g(scene->lock);
+    HIP_TRY(hipSetDevice(scene->device));
+    hipStream_t sm = (hipStream_t)stream;
+    // host: transform records with sin / cos from the host libm, as at creation (types.rs:200 evaluates them per ray)
+    bool loose = false;
+    host_make_xforms(scene->desc_entities.data(), scene->tlas_perm, translations, rotations, scene->xforms_host, loose);
+    if (scene->xforms_host.size() != scene->xforms_words) return set_error(RT_E_INVALID, "rt_scene_update_transforms: internal size mismatch");
+    Word4* xforms_dev = const_cast<Word4*>(scene->view.xforms);
+    DevNode* nodes_dev = const_cast<DevNode*>(scene->view.nodes);
+    DevEntity* entities_dev = const_cast<DevEntity*>(scene->view.entities);
+    HIP_TRY(hipMemcpyAsync(xforms_dev, scene->xforms_host.data(), scene->xforms_host.size() * sizeof(Word4), hipMemcpyHostToDevice, sm));
+    // device: entity boxes, then the tree bottom-up (one launch per level, deepest first), then the root box
+    const uint32_t n = scene->view.entity_count;
+    hipLaunchKernelGGL(refit_entities_kernel, dim3((n + 255) / 256), dim3(256), 0, sm, entities_dev, (const Word4*)xforms_dev, scene->view.meshes, scene->ent_box_dev, n);
+    HIP_TRY_SYNC(hipGetLastError(), sm);
+    for (size_t l = 0; l + 1 < scene->refit_level_start.size(); l++) {
+        const uint32_t first = scene->refit_level_start[l], count = scene->refit_level_start[l + 1] - first;
+        if (count == 0) continue;
+        hipLaunchKernelGGL(refit_level_kernel, dim3((count + 255) / 256), dim3(256), 0, sm, nodes_dev, scene->refit_dev, first, count, (const float*)scene->ent_box_dev);
+        HIP_TRY_SYNC(hipGetLastError(), sm);
+    }
+    float* root_dev = scene->ent_box_dev + (size_t)n * 8;
+    hipLaunchKernelGGL(refit_root_kernel, dim3(1), dim3(1), 0, sm, (const DevNode*)nodes_dev, scene->view.tlas_root_ref, n, (const float*)scene->ent_box_dev, root_dev);
+    HIP_TRY_SYNC(hipGetLastError(), sm);
+    float root[6];
+    HIP_TRY_SYNC(hipMemcpyAsync(root, root_dev, sizeof(root), hipMemcpyDeviceToHost, sm), sm);
+    HIP_TRY(hipStreamSynchronize(sm));
+    for (int k = 0; k < 3; k++) { scene->view.tlas_min[k] = root[k]; scene->view.tlas_max[k] = root[3 + k]; }
+    scene->view.loose_boxes = loose ? 1u : 0u;
+    scene->view.coc_rel_max = host_coc_rel_max(scene->camera, scene->view.tlas_min, scene->view.tlas_max, n > 0);
     return RT_OK;
 }
 

@@ -180,8 +180,12 @@ struct Emitter {
     uint32_t depth = 0;      // max inner nodes on a root-to-leaf path
 
     // the tree as it will be emitted: one record per inner node, children = leaf refs or records
-    struct ENode { Box lb, rb; uint32_t l, r; bool l_inner, r_inner; };
+    // l_src / r_src: where a child's box comes from when the tree is refitted (rt_scene_update_transforms): the union of the
+    // object boxes of a range of positions (count > 0: a reference leaf - or, below a leaf of more than RT_LEAF_MAX objects,
+    // the whole of that leaf), or the union of the two boxes of the child's own record (count == 0).
+    struct ENode { Box lb, rb; uint32_t l, r; bool l_inner, r_inner; uint32_t level; uint32_t l_src_first, l_src_count, r_src_first, r_src_count; };
     std::vector<ENode> en;
+    std::vector<uint32_t> number;      // record index of every ENode in the scene's node array (after write())
     uint32_t root = 0; bool root_inner = false;
 
     explicit Emitter(const Tree& tree) : t(tree) { root = build(0, 0, root_inner); }
@@ -198,25 +202,26 @@ struct Emitter {
     // A leaf of more than RT_LEAF_MAX objects (only when a split left one side
     // empty, bvh.rs:169) becomes a small subtree whose boxes all equal the leaf's
     // box: every object is still tested exactly when that box is hit.
-    uint32_t build_leaf(uint32_t first, uint32_t count, const Box& box, uint32_t level, bool& inner) {
+    uint32_t build_leaf(uint32_t first, uint32_t count, const Box& box, uint32_t level, bool& inner, uint32_t src_first, uint32_t src_count) {
         if (count <= RT_LEAF_MAX) { if (level > depth) depth = level; inner = false; return leaf_ref(first, count); }
         const uint32_t me = (uint32_t)en.size(); en.emplace_back();
         const uint32_t half = count / 2;
         bool li, ri;
-        const uint32_t l = build_leaf(first, half, box, level + 1, li);
-        const uint32_t r = build_leaf(first + half, count - half, box, level + 1, ri);
-        en[me] = ENode{box, box, l, r, li, ri};
+        const uint32_t l = build_leaf(first, half, box, level + 1, li, src_first, src_count);
+        const uint32_t r = build_leaf(first + half, count - half, box, level + 1, ri, src_first, src_count);
+        en[me] = ENode{box, box, l, r, li, ri, level, src_first, src_count, src_first, src_count};      // both boxes = the whole leaf's
         inner = true;
         return me;
     }
     uint32_t build(int32_t ni, uint32_t level, bool& inner) {
         const TreeNode n = t.nodes[ni];
-        if (n.left < 0) return build_leaf(n.first, n.count, n.box, level, inner);
+        if (n.left < 0) return build_leaf(n.first, n.count, n.box, level, inner, n.first, n.count);
         const uint32_t me = (uint32_t)en.size(); en.emplace_back();
         bool li, ri;
         const uint32_t l = build(n.left, level + 1, li);
         const uint32_t r = build(n.right, level + 1, ri);
-        en[me] = ENode{t.nodes[n.left].box, t.nodes[n.right].box, l, r, li, ri};
+        const TreeNode& cl = t.nodes[n.left]; const TreeNode& cr = t.nodes[n.right];
+        en[me] = ENode{cl.box, cr.box, l, r, li, ri, level, cl.first, cl.left < 0 ? cl.count : 0u, cr.first, cr.left < 0 ? cr.count : 0u};
         inner = true;
         return me;
     }
@@ -226,7 +231,7 @@ struct Emitter {
     // parent) from nodes[cold_base] on.  Returns the ref of the root.
     uint32_t write(std::vector<DevNode>& nodes, uint32_t hot_base, uint32_t n_hot, uint32_t cold_base) {
         if (!root_inner) return root;
-        std::vector<uint32_t> number(en.size(), RT_NONE_U32);
+        number.assign(en.size(), RT_NONE_U32);
         std::vector<uint32_t> order{root};
         for (size_t i = 0; i < order.size() && i < n_hot; i++) {
             const ENode& e = en[order[i]];
@@ -625,7 +630,27 @@ int build_flat_scene(const RtSceneDesc* d, FlatScene& out, std::string& err) {
         uint32_t hot_at = 0, cold_at = (uint32_t)n_hot;
         for (size_t k = 0; k < emitters.size(); k++) {
             const uint32_t ref = emitters[k]->write(out.nodes, hot_at, hot[k], cold_at);
-            if (k == 0) v.tlas_root_ref = ref; else out.meshes[k - 1].w[0].u[3] = ref;
+            if (k == 0) {
+                v.tlas_root_ref = ref;
+                // refit tables of the TLAS (rt_scene_update_transforms): records by level, deepest first
+                const Emitter& em = *emitters[0];
+                uint32_t levels = 0;
+                for (const Emitter::ENode& e : em.en) levels = std::max(levels, e.level + 1);
+                std::vector<std::vector<uint32_t>> by_level(levels);
+                for (uint32_t i = 0; i < em.en.size(); i++) by_level[em.en[i].level].push_back(i);
+                out.refit_level_start.assign(1, 0u);
+                for (uint32_t l = levels; l-- > 0;) {
+                    for (uint32_t i : by_level[l]) {
+                        const Emitter::ENode& e = em.en[i];
+                        RefitRec r{};
+                        r.node = em.number[i];
+                        r.l_first = e.l_src_first; r.l_count = e.l_src_count; r.l_child = e.l_inner ? em.number[e.l] : 0u;
+                        r.r_first = e.r_src_first; r.r_count = e.r_src_count; r.r_child = e.r_inner ? em.number[e.r] : 0u;
+                        out.refit.push_back(r);
+                    }
+                    out.refit_level_start.push_back((uint32_t)out.refit.size());
+                }
+            } else out.meshes[k - 1].w[0].u[3] = ref;
             hot_at += hot[k]; cold_at += (uint32_t)emitters[k]->en.size() - hot[k];
             emitters[k].reset();
         }
@@ -644,7 +669,9 @@ int build_flat_scene(const RtSceneDesc* d, FlatScene& out, std::string& err) {
     out.tlas_order.resize(n_ent);
     for (uint32_t k = 0; k < pos_order.size(); k++) { erank[pos_order[k]] = k; out.tlas_order[k] = tlas.perm[pos_order[k]]; }
     out.entities.resize(n_ent);
+    out.tlas_perm = tlas.perm;
     uint64_t inst_tris = 0;
+    uint32_t xform_at = 0;
     for (uint64_t p = 0; p < n_ent; p++) {
         const uint32_t ei = tlas.perm[p];
         const RtEntity& e = d->entities[ei];
@@ -658,33 +685,17 @@ int build_flat_scene(const RtSceneDesc* d, FlatScene& out, std::string& err) {
         de.w[0].f[3] = radius;
         de.w[1].u[0] = e.hitable_kind | (e.translation_count << 8) | (e.rotation_count << 16);
         de.w[1].u[1] = hidx;
-        de.w[1].u[2] = (uint32_t)out.xforms.size();
+        de.w[1].u[2] = xform_at;                       // (host_make_xforms lays the records out in this order)
+        xform_at += e.translation_count + 2u * e.rotation_count;
         de.w[1].u[3] = mat;
         de.w[2].u[0] = tex; de.w[2].u[1] = ei; de.w[2].i[2] = e.id; de.w[2].u[3] = erank[p];
-        for (uint32_t k = 0; k < e.translation_count; k++) {
-            const RtV3& t = d->translations[e.translation_first + k];
-            Word4 w; w.f[0] = t.x; w.f[1] = t.y; w.f[2] = t.z; w.f[3] = 0.0f;
-            out.xforms.push_back(w);
-        }
-        for (uint32_t k = 0; k < e.rotation_count; k++) {
-            const RtRotation& r = d->rotations[e.rotation_first + k];
-            Word4 w0, w1;
-            w0.f[0] = r.axis.x; w0.f[1] = r.axis.y; w0.f[2] = r.axis.z; w0.f[3] = cosf(-r.theta);
-            w1.f[0] = sinf(-r.theta); w1.f[1] = cosf(r.theta); w1.f[2] = sinf(r.theta);
-            // exact identity (see rotate_cs_id in render.hip): both directions, tame axis
-            const bool identity = w0.f[3] == 1.0f && w1.f[0] == 0.0f && w1.f[1] == 1.0f && w1.f[2] == 0.0f &&
-                                  fabsf(r.axis.x) <= 2.0f && fabsf(r.axis.y) <= 2.0f && fabsf(r.axis.z) <= 2.0f;
-            w1.u[3] = identity ? 1u : 0u;
-            out.xforms.push_back(w0); out.xforms.push_back(w1);
-            // rotate_about_axis assumes a unit axis (types.rs:190); with any other axis the map is no
-            // rotation, Entity::hit's inverse is not its inverse, and the reference's entity boxes
-            // (calculate_origin_aabb) no longer bound what Entity::hit finds -> see loose_boxes
-            const float len2 = r.axis.x * r.axis.x + r.axis.y * r.axis.y + r.axis.z * r.axis.z;
-            if (!identity && !(fabsf(len2 - 1.0f) <= 1.0e-4f)) v.loose_boxes = 1;
-        }
     }
     out.info.instanced_triangle_count = inst_tris;
-    if (out.xforms.empty()) out.xforms.emplace_back();
+    {
+        bool loose = false;
+        host_make_xforms(d->entities, tlas.perm, d->translations, d->rotations, out.xforms, loose);
+        v.loose_boxes = loose ? 1u : 0u;
+    }
 
     lap("entity records");
     // ---- planes / materials / textures / lights ---------------------------------
@@ -703,27 +714,10 @@ int build_flat_scene(const RtSceneDesc* d, FlatScene& out, std::string& err) {
     // Circle of confusion of any primary hit, bounded from the TLAS root box: camera rays meet the focal plane at
     // t = 1 and t is the depth along the view axis over the focus distance, rays of one pixel are 2 R |1 - t| apart at t
     // and the image is t |horizontal| wide there.  Decides whether a launch needs the lens-cell round shape at all.
-    v.coc_rel_max = INFINITY;
-    if (!(d->camera.lens_radius > 0.0f)) v.coc_rel_max = 0.0f;
-    else if (n_ent > 0 && !box_is_infinite(tlas.nodes[0].box)) {
-        const RtCamera& c = d->camera;
-        const double ctr[3] = {c.lower_left_corner.x + 0.5 * c.horizontal.x + 0.5 * c.vertical.x - c.origin.x,
-                               c.lower_left_corner.y + 0.5 * c.horizontal.y + 0.5 * c.vertical.y - c.origin.y,
-                               c.lower_left_corner.z + 0.5 * c.horizontal.z + 0.5 * c.vertical.z - c.origin.z};
-        const double f = std::sqrt(ctr[0] * ctr[0] + ctr[1] * ctr[1] + ctr[2] * ctr[2]);
-        const double hlen = std::sqrt((double)c.horizontal.x * c.horizontal.x + (double)c.horizontal.y * c.horizontal.y + (double)c.horizontal.z * c.horizontal.z);
+    {
         const Box& rb = tlas.nodes[0].box;
-        double zmin = 1e300, zmax = -1e300;
-        for (int k = 0; k < 8; k++) {
-            const double px = (k & 1) ? rb.hi.x : rb.lo.x, py = (k & 2) ? rb.hi.y : rb.lo.y, pz = (k & 4) ? rb.hi.z : rb.lo.z;
-            const double z = ((px - c.origin.x) * ctr[0] + (py - c.origin.y) * ctr[1] + (pz - c.origin.z) * ctr[2]) / f;
-            zmin = std::min(zmin, z); zmax = std::max(zmax, z);
-        }
-        if (f > 0.0 && hlen > 0.0 && zmin > 1e-6 * f && std::isfinite(zmax)) {
-            const double t_lo = zmin / f, t_hi = zmax / f;
-            const double worst = std::max(std::fabs(1.0 - t_lo) / t_lo, std::fabs(1.0 - t_hi) / t_hi);
-            v.coc_rel_max = (float)(1.05 * 2.0 * c.lens_radius * worst / hlen);
-        }
+        const float lo[3] = {rb.lo.x, rb.lo.y, rb.lo.z}, hi[3] = {rb.hi.x, rb.hi.y, rb.hi.z};
+        v.coc_rel_max = host_coc_rel_max(d->camera, lo, hi, n_ent > 0);
     }
     v.rich_shading = 0;
     for (uint64_t i = 0; i < d->light_count; i++) if (d->lights[i].kind == RT_LIGHT_LAMP) v.rich_shading = 1;
@@ -767,6 +761,63 @@ int build_flat_scene(const RtSceneDesc* d, FlatScene& out, std::string& err) {
 
     lap("materials, textures, lights");
     return RT_OK;
+}
+
+void host_make_xforms(const RtEntity* entities, const std::vector<uint32_t>& tlas_perm, const RtV3* translations, const RtRotation* rotations,
+                      std::vector<Word4>& xforms, bool& loose_boxes) {
+    xforms.clear();
+    loose_boxes = false;
+    for (uint32_t ei : tlas_perm) {
+        const RtEntity& e = entities[ei];
+        for (uint32_t k = 0; k < e.translation_count; k++) {
+            const RtV3& t = translations[e.translation_first + k];
+            Word4 w; w.f[0] = t.x; w.f[1] = t.y; w.f[2] = t.z; w.f[3] = 0.0f;
+            xforms.push_back(w);
+        }
+        for (uint32_t k = 0; k < e.rotation_count; k++) {
+            const RtRotation& r = rotations[e.rotation_first + k];
+            Word4 w0, w1;
+            w0.f[0] = r.axis.x; w0.f[1] = r.axis.y; w0.f[2] = r.axis.z; w0.f[3] = cosf(-r.theta);
+            w1.f[0] = sinf(-r.theta); w1.f[1] = cosf(r.theta); w1.f[2] = sinf(r.theta);
+            // exact identity (see rotate_cs_id in render.hip): both directions, tame axis
+            const bool identity = w0.f[3] == 1.0f && w1.f[0] == 0.0f && w1.f[1] == 1.0f && w1.f[2] == 0.0f &&
+                                  fabsf(r.axis.x) <= 2.0f && fabsf(r.axis.y) <= 2.0f && fabsf(r.axis.z) <= 2.0f;
+            w1.u[3] = identity ? 1u : 0u;
+            xforms.push_back(w0); xforms.push_back(w1);
+            // rotate_about_axis assumes a unit axis (types.rs:190); with any other axis the map is no
+            // rotation, Entity::hit's inverse is not its inverse, and the reference's entity boxes
+            // (calculate_origin_aabb) no longer bound what Entity::hit finds -> see loose_boxes
+            const float len2 = r.axis.x * r.axis.x + r.axis.y * r.axis.y + r.axis.z * r.axis.z;
+            if (!identity && !(fabsf(len2 - 1.0f) <= 1.0e-4f)) loose_boxes = true;
+        }
+    }
+    if (xforms.empty()) xforms.emplace_back();
+}
+
+// Circle of confusion of any primary hit, bounded from the TLAS root box: camera rays meet the focal plane at
+// t = 1 and t is the depth along the view axis over the focus distance, rays of one pixel are 2 R |1 - t| apart at t
+// and the image is t |horizontal| wide there.  Decides whether a launch needs the lens-cell round shape at all.
+float host_coc_rel_max(const RtCamera& c, const float lo[3], const float hi[3], bool any_entity) {
+    if (!(c.lens_radius > 0.0f)) return 0.0f;
+    const bool infinite = lo[0] == -INFINITY && lo[1] == -INFINITY && lo[2] == -INFINITY && hi[0] == INFINITY && hi[1] == INFINITY && hi[2] == INFINITY;
+    if (!any_entity || infinite) return INFINITY;
+    const double ctr[3] = {c.lower_left_corner.x + 0.5 * c.horizontal.x + 0.5 * c.vertical.x - c.origin.x,
+                           c.lower_left_corner.y + 0.5 * c.horizontal.y + 0.5 * c.vertical.y - c.origin.y,
+                           c.lower_left_corner.z + 0.5 * c.horizontal.z + 0.5 * c.vertical.z - c.origin.z};
+    const double f = std::sqrt(ctr[0] * ctr[0] + ctr[1] * ctr[1] + ctr[2] * ctr[2]);
+    const double hlen = std::sqrt((double)c.horizontal.x * c.horizontal.x + (double)c.horizontal.y * c.horizontal.y + (double)c.horizontal.z * c.horizontal.z);
+    double zmin = 1e300, zmax = -1e300;
+    for (int k = 0; k < 8; k++) {
+        const double px = (k & 1) ? hi[0] : lo[0], py = (k & 2) ? hi[1] : lo[1], pz = (k & 4) ? hi[2] : lo[2];
+        const double z = ((px - c.origin.x) * ctr[0] + (py - c.origin.y) * ctr[1] + (pz - c.origin.z) * ctr[2]) / f;
+        zmin = std::min(zmin, z); zmax = std::max(zmax, z);
+    }
+    if (f > 0.0 && hlen > 0.0 && zmin > 1e-6 * f && std::isfinite(zmax)) {
+        const double t_lo = zmin / f, t_hi = zmax / f;
+        const double worst = std::max(std::fabs(1.0 - t_lo) / t_lo, std::fabs(1.0 - t_hi) / t_hi);
+        return (float)(1.05 * 2.0 * c.lens_radius * worst / hlen);
+    }
+    return INFINITY;
 }
 
 int host_create_render_chunks(uint32_t width, uint32_t height, uint32_t count_x, uint32_t count_y, RtRenderChunk* out, uint32_t capacity) {

@@ -10,6 +10,11 @@
 #include "../../include/rt_hip.h"
 #include "device_scene.h"
 
+// One TLAS node record and where its two boxes come from when the tree is refitted after a change of the entity transforms
+// (rt_scene_update_transforms): count > 0: the union of the entity boxes [first, first + count) (TLAS leaf order);
+// count == 0: the union of the two boxes of node record `child`.  Records are listed deepest level first.
+struct RefitRec { uint32_t node, l_first, l_count, l_child, r_first, r_count, r_child, pad; };
+
 struct FlatScene {
     std::vector<DevNode> nodes;
     std::vector<DevEntity> entities;
@@ -30,7 +35,19 @@ struct FlatScene {
     // and of each BLAS, for rt_scene_bvh_order
     std::vector<uint32_t> tlas_order;
     std::vector<std::vector<uint32_t>> blas_order;
+    // refit of the TLAS on the device
+    std::vector<RefitRec> refit;
+    std::vector<uint32_t> refit_level_start;   // boundaries of the levels in `refit` (deepest first)
+    std::vector<uint32_t> tlas_perm;           // TLAS position -> entity index of the description
 };
+
+// Host half of rt_scene_update_transforms: the transform records of every entity (layout of FlatScene::xforms) for new
+// translations / rotations, with sin / cos evaluated by the host libm like at creation; also whether any rotation axis is
+// not of unit length (DevSceneView::loose_boxes).
+void host_make_xforms(const RtEntity* entities, const std::vector<uint32_t>& tlas_perm, const RtV3* translations, const RtRotation* rotations,
+                      std::vector<Word4>& xforms, bool& loose_boxes);
+// DevSceneView::coc_rel_max from the camera and the TLAS root box
+float host_coc_rel_max(const RtCamera& camera, const float root_min[3], const float root_max[3], bool any_entity);
 
 // Returns RT_OK or a negative code with `error` filled.
 int build_flat_scene(const RtSceneDesc* desc, FlatScene& out, std::string& error);

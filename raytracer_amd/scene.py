@@ -275,6 +275,13 @@ class Scene:
         "fine_split" -1 / 0 / 1, "round_units" 1 / 2 / 4 / 8 and "lens_coc_px" only change the schedule."""
         self._check(self._lib.rt_scene_set_option(self._h, self.OPTIONS[name], float(value)))
 
+    def update_transforms(self, builder, stream=None):
+        """rt_scene_update_transforms: take the translations / rotations of `builder` (a SceneBuilder describing the same
+        entities, moved) and refit the TLAS on the device."""
+        d = builder.desc().contents
+        self._check(self._lib.rt_scene_update_transforms(self._h, C.cast(d.translations, C.c_void_p), d.translation_count,
+                                                         C.cast(d.rotations, C.c_void_p), d.rotation_count, stream))
+
     def info(self):
         out = RtSceneInfo()
         self._check(self._lib.rt_scene_info(self._h, C.byref(out)))
