@@ -64,6 +64,7 @@ WORKLOADS = {
     "weekend-400x225-16spp": ("Random Spheres", 400, 225, 16, 8, 0.1, None),            # configs[0]
     "dreadnaught-1080p-128spp": ("Dreadnaught", 1920, 1080, 128, 8, 0.1, None),         # configs[2]: the target scene
     "meshdemo-4k-1024spp": ("Mesh", 3840, 2160, 1024, 8, 0.1, None),                    # configs[3]
+    "meshdemo-4k-64spp": ("Mesh", 3840, 2160, 64, 8, 0.1, None),                        # configs[3] at 64 spp: quick A/B runs only
     "dootdoot-4k-64spp": ("Doot Doot", 3840, 2160, 64, 8, 0.1, {"Count": 30, "Spacing": 30}),  # configs[4] geometry
     "dootdoot-4k-4096spp": ("Doot Doot", 3840, 2160, 4096, 8, 0.1, {"Count": 30, "Spacing": 30}),  # configs[4] in full (~12 s per frame on one GPU)
 }

@@ -54,6 +54,9 @@
 #define RT_QUEUES 16u            /* block counters per launch, one cache line each */
 #endif
 #define RT_MAX_REFLECTIONS 31u
+#ifdef RT_PHASE_TIME            /* (make time: a flavour of the diagnostics build) */
+#define RT_PHASE_STATS
+#endif
 
 
 
@@ -599,9 +602,20 @@ template <int STRIDE> __device__ __forceinline__ float seq_sum8(float c) {
 
 // Diagnostics build (make stats): per phase, how many lanes and how many wave
 // passes went through it; lane utilisation of a phase = lanes / (64 * passes).
+// Second diagnostics build (make time, -DRT_PHASE_TIME): where a wave's CYCLES go - s_memtime at every change of phase.
+#ifdef RT_PHASE_TIME
+enum { TM_OTHER = 0, TM_NODE, TM_LEAF_TRI, TM_LEAF_TLAS, TM_SHADE, TM_ROUNDS, TM_CLAIM, TM_COUNT };
+#define TM(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tm_acc[tm_cur] += now_ - tm_last; tm_last = now_; tm_cur = (i); } while (0)
+#else
+#define TM(i) do { } while (0)
+#endif
 #ifdef RT_PHASE_STATS
 enum { PH_NODE = 0, PH_TRI, PH_ENTITY, PH_SHADE, PH_SHADE_PATH_HIT, PH_SHADE_SHADOW_HIT, PH_STAGE_A, PH_STAGE_C, PH_TRACE_INIT, PH_BURST, PH_LEAF_TRI, PH_LEAF_TLAS, PH_OUTER, PH_POP_INST, PH_COUNT };
+#ifdef RT_PHASE_TIME
+#define PH(i) do { } while (0)
+#else
 #define PH(i) do { const unsigned long long m_ = __ballot(1); ph_lanes[i]++; ph_waves[i] += (lane == (uint32_t)(__ffsll((long long)m_) - 1)); } while (0)
+#endif
 #else
 #define PH(i) do { } while (0)
 #endif
@@ -634,8 +648,11 @@ render_kernel(const DevSceneView S, const RenderParams P) {
 
     uint32_t n_primary = 0, n_secondary = 0, n_shadow = 0, n_samples = 0;
     uint32_t queue = (blockIdx.x * (RT_BLOCK / 64u) + (threadIdx.x >> 6)) % RT_QUEUES;      // this wave's current block counter
-#ifdef RT_PHASE_STATS
+#if defined(RT_PHASE_STATS) && !defined(RT_PHASE_TIME)
     uint32_t ph_lanes[PH_COUNT] = {}, ph_waves[PH_COUNT] = {};
+#endif
+#ifdef RT_PHASE_TIME
+    unsigned long long tm_acc[TM_COUNT] = {}, tm_last = __builtin_amdgcn_s_memtime(); int tm_cur = TM_OTHER;
 #endif
 
     // Lane state between two rays.  PATH / SHADOW: a ray of that kind is in flight
@@ -677,6 +694,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
 
     for (;;) {
         PH(PH_OUTER);
+        TM(TM_CLAIM);
         // ================= next block of work items: all lanes of the wave together ======
         if (__ballot(state != NEED_BLOCK && state != FINISHED) == 0ull) {
             if (__ballot(state == NEED_BLOCK) != 0ull) {          // (all lanes of a wave are in the same of the two states)
@@ -729,6 +747,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
         if (!tracing && state != NEED_BLOCK && state != FINISHED) {
             // ================= shading of the ray that just finished =====================
             PH(PH_SHADE);
+            TM(TM_SHADE);
             if (state == SHADOW) {
                 // cast_light_ray_to_lamp, implementation.rs:535-552
                 n_shadow++;
@@ -885,6 +904,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
         // they stay together where the 64 lens points of one pixel would spread over the circle of confusion
         // (weekend +9 %, mesh_demo +18 %).  A lane then owns one pixel of one unit and adds its samples into
         // the output slot round by round: the same additions in the same order.
+        TM(TM_ROUNDS);
         if (__ballot(tracing || state != NEED_SAMPLE) == 0ull) {        // wave-uniform: every lane has finished its sample
             // lane = (unit of the group, sample of the unit, pixel of the round); all sizes are powers of two
             const uint32_t l_shift = P.unit_len == 1u ? 0u : RT_SEGMENT_SHIFT, k_shift = P.round_units_shift;
@@ -969,6 +989,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
             // ================= start the traversal of the new ray ==========================
             if (state == PATH || state == SHADOW) {
                 PH(PH_TRACE_INIT);
+                TM(TM_OTHER);
                 const bool shadow = state == SHADOW;
                 o = shadow ? hp : ro;
                 d = shadow ? -ldir : rd;
@@ -1006,6 +1027,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
         for (;;) {
             if (tracing) {
                 PH(PH_BURST);
+                TM(TM_NODE);
                 // ---- phase 1: walk inner nodes until this lane holds a leaf (RT_NONE has
                 // the leaf bit set and ends the walk too).  One 64-byte record = two boxes.
                 while (cur < RT_REF_LEAF_BIT) {
@@ -1037,6 +1059,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                     const uint32_t count = ((cur >> RT_REF_COUNT_SHIFT) & 7u) + 1u;
                     if (MESH && inst_sp != RT_NONE) {
                         PH(PH_LEAF_TRI);
+                        TM(TM_LEAF_TRI);
                         // try_hit_tri, mesh.rs:18-76 (normal precomputed with the same ops)
                         for (uint32_t k = 0; k < count; k++) {
                             PH(PH_TRI);
@@ -1070,6 +1093,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                         // TLAS leaf: its entities in order; a mesh entity defers the rest of the
                         // leaf and turns the walk into its BLAS.
                         PH(PH_LEAF_TLAS);
+                        TM(TM_LEAF_TLAS);
                         const bool shadow = state == SHADOW;
                         const F3 wo = shadow ? hp : ro, wd = shadow ? -ldir : rd;
                         bool entered = false;
@@ -1151,7 +1175,10 @@ render_kernel(const DevSceneView S, const RenderParams P) {
         }
     }
 
-#ifdef RT_PHASE_STATS
+#ifdef RT_PHASE_TIME
+    TM(TM_OTHER);
+    for (int k = 0; k < TM_COUNT; k++) if (lane == 0) { atomicAdd(P.phase_stats + 2 * k, tm_acc[k]); atomicAdd(P.phase_stats + 2 * k + 1, 1ull); }
+#elif defined(RT_PHASE_STATS)
     for (int k = 0; k < PH_COUNT; k++) {
         uint32_t a = ph_lanes[k], b = ph_waves[k];
         for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off, 64); b += __shfl_down(b, off, 64); }
@@ -1729,9 +1756,17 @@ int enqueue_accumulate(RtScene* scene, Workspace& ws, const RtSettings* st, cons
             unsigned long long h[PH_COUNT * 2];
             HIP_TRY(hipMemcpyAsync(h, phase_dev, sizeof(h), hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));
+#ifdef RT_PHASE_TIME
+            static const char* tnames[TM_COUNT] = {"other", "node walk", "leaf: triangles", "leaf: entities", "shading", "rounds", "claim / idle"};
+            unsigned long long total = 0;
+            for (int k = 0; k < TM_COUNT; k++) total += h[2 * k];
+            for (int k = 0; k < TM_COUNT; k++)
+                fprintf(stderr, "time  %-18s %6.2f %% of the wave cycles (%llu waves)\n", tnames[k], total ? 100.0 * (double)h[2 * k] / (double)total : 0.0, h[2 * k + 1]);
+#else
             static const char* names[PH_COUNT] = {"node", "tri", "entity", "shade", "shade_path_hit", "shade_shadow_hit", "stage_a", "stage_c", "trace_init", "burst", "leaf_tri", "leaf_tlas", "outer", "pop_inst"};
             for (int k = 0; k < PH_COUNT; k++)
                 fprintf(stderr, "phase %-18s lanes %14llu passes %12llu util %.3f\n", names[k], h[2 * k], h[2 * k + 1], h[2 * k + 1] ? (double)h[2 * k] / (64.0 * (double)h[2 * k + 1]) : 0.0);
+#endif
         }
 #endif
         if (profiling) {
