@@ -200,6 +200,9 @@ __device__ __forceinline__ void slab2(const Word4& a, const Word4& b, const Word
     hr = slab(a.f[1], a.f[3], b.f[1], b.f[3], c.f[1], c.f[3], o, inv, t_min, t_max, er);
 }
 
+// reference visit rank of the entity at TLAS position `ei`: decides exact ties in t between two entities (implementation.rs:415)
+__device__ __forceinline__ uint32_t entity_rank(const DevSceneView& S, uint32_t ei) { return ldw(S.entities[ei].w + 2).u[3]; }
+
 // Entity::hit's world -> entity ray transform, implementation.rs:288-294
 // XFORMS = false: every entity of the scene has exactly one translation and no rotation
 // (DevSceneView::general_xforms == 0), so only the inline translation is ever needed.
@@ -682,8 +685,8 @@ render_kernel(const DevSceneView S, const RenderParams P) {
     // Plane::hit / MeshBvhRoot::try_hit (sphere.rs:36-53, plane.rs:59-90, mesh.rs:92-99).
     F3 o = f3(0, 0, 0), d = f3(0, 0, 1), inv = f3(0, 0, 0);
     float t_min = 0.0f, t_max = 0.0f, best_t = 0.0f;
-    Hit best; best.t = 0.0f; best.ent = RT_NONE; best.tri = RT_NONE; best.erank = 0;
-    uint32_t cur = RT_NONE, sp = 0, inst_sp = RT_NONE, tri_base = 0, cur_ent = 0, cur_erank = 0;
+    Hit best; best.t = 0.0f; best.ent = RT_NONE; best.tri = RT_NONE; best.erank = 0;      // (erank: unused here, ranks are fetched on ties)
+    uint32_t cur = RT_NONE, sp = 0, inst_sp = RT_NONE, tri_base = 0, cur_ent = 0;
 
     // Node cache: the scene's first S.lds_nodes records (the top levels of the TLAS and of every BLAS,
     // scene_build.cpp) are read from LDS instead of through the vector memory path: the texture
@@ -1003,7 +1006,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                     stack[(stack_cap + 2u) * RT_BLOCK] = __float_as_uint(inv.z);
                 }
                 t_min = shadow ? closest : RT_BIAS; t_max = shadow ? l_t : RT_F32_MAX;
-                best.t = t_max; best.ent = RT_NONE; best.tri = RT_NONE; best.erank = 0; best_t = t_max;
+                best.t = t_max; best.ent = RT_NONE; best.tri = RT_NONE; best_t = t_max;
                 sp = 0; inst_sp = RT_NONE;
                 float e;
                 cur = slab(S.tlas_min[0], S.tlas_min[1], S.tlas_min[2], S.tlas_max[0], S.tlas_max[1], S.tlas_max[2], o, inv, t_min, best_t, e)
@@ -1087,10 +1090,11 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                             if (!better && t == best.t) {
                                 // exact tie: the reference keeps the candidate it visits first
                                 // (implementation.rs:415, mesh.rs:96-98); ranks are only fetched here
-                                better = cur_erank < best.erank ||
-                                         (cur_erank == best.erank && best.tri != RT_NONE && S.tri_rank[ti] < S.tri_rank[best.tri]);
+                                // (ranks are fetched here only: an exact tie is rare, a hit is not)
+                                better = cur_ent == best.ent ? (best.tri != RT_NONE && S.tri_rank[ti] < S.tri_rank[best.tri])
+                                                             : entity_rank(S, cur_ent) < entity_rank(S, best.ent);
                             }
-                            if (better) { best.t = t; best.ent = cur_ent; best.tri = ti; best.erank = cur_erank; best_t = fminf(t * RT_CULL_SLACK, t_max); }
+                            if (better) { best.t = t; best.ent = cur_ent; best.tri = ti; best_t = fminf(t * RT_CULL_SLACK, t_max); }
                         }
                         cur = pop();
                     } else {
@@ -1149,15 +1153,14 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                                     inst_sp = sp;
                                     o = eo; d = ed; inv = einv;
                                     tri_base = m0.u[1];
-                                    cur_ent = ei; cur_erank = ldw(ew + 2).u[3];
+                                    cur_ent = ei;
                                     cur = m0.u[3];
                                     entered = true;
                                 }
                             }
                             if (hit) {
-                                const uint32_t erank = ldw(ew + 2).u[3];
-                                if (best.ent == RT_NONE || t < best.t || (t == best.t && erank < best.erank)) {
-                                    best.t = t; best.ent = ei; best.tri = RT_NONE; best.erank = erank; best_t = fminf(t * RT_CULL_SLACK, t_max);
+                                if (best.ent == RT_NONE || t < best.t || (t == best.t && entity_rank(S, ei) < entity_rank(S, best.ent))) {
+                                    best.t = t; best.ent = ei; best.tri = RT_NONE; best_t = fminf(t * RT_CULL_SLACK, t_max);
                                 }
                             }
                         }
