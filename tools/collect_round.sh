@@ -1,12 +1,21 @@
+#!/bin/bash
+# Everything profiles/ holds for one round, in one GPU call: tools/collect_round.sh <tag>   (e.g. r02_v20)
+#   gpurun_out/<tag>/stats      rocprofv3 --kernel-trace --stats of the default bench command
+#   gpurun_out/<tag>/pmc*       PMC passes (one rocprofv3 --pmc run each, never combined with a trace) -> <tag>_pmc_<workload>.json
+#   gpurun_out/<tag>/bench_*    the bench line of every BASELINE config
 set -e
+TAG=$1
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-mkdir -p gpurun_out/bench10 gpurun_out/prof_v10
-timeout -k 10 200 python tools/emulate_ranks.py
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_v10 -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/prof_v10/bench.log 2>&1
-echo prof ok
-rm -rf gpurun_out/pmc_v10; tools/pmc_passes.sh gpurun_out/pmc_v10 "sq1 sq2 sq3 tcp tcc1 tcc2 grbm"
-python tools/pmc_summary.py gpurun_out/pmc_v10 render_kernel > gpurun_out/pmc_v10.json
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/stats.log 2>&1
+echo "stats ok"
+for w in weekend-1080p-256spp dreadnaught-1080p-128spp meshdemo-4k-64spp dootdoot-4k-64spp; do
+  rm -rf $OUT/pmc_$w
+  tools/pmc_passes.sh $OUT/pmc_$w "sq1 sq2 sq3 tcp tcc1 tcc2 grbm" --workload $w --no-target-scene
+  python tools/pmc_summary.py $OUT/pmc_$w render_kernel > $OUT/pmc_$w.json
+done
 for w in weekend-1080p-256spp weekend-400x225-16spp dreadnaught-1080p-128spp dootdoot-4k-64spp meshdemo-4k-1024spp; do
-  timeout -k 10 500 python bench.py --workload $w --steps 3 --warmup 1 > gpurun_out/bench10/bench_r01_$w.json 2> gpurun_out/bench10/$w.err
-  python -c "import json; d=json.loads(open('gpurun_out/bench10/bench_r01_$w.json').read().strip().splitlines()[-1]); print(d['config']['workload'], d['value'], d['ms_per_step'], d['roofline']['frac'], d['cpu_baseline']['value'], d['gpu_over_cpu'])"
+  timeout -k 10 500 python bench.py --workload $w --steps 3 --warmup 1 --no-target-scene > $OUT/bench_$w.json 2> $OUT/bench_$w.err
+  python -c "import json; d=json.loads(open('$OUT/bench_$w.json').read().strip().splitlines()[-1]); print(d['config']['workload'], d['value'], d['ms_per_step'], d['roofline']['frac'], d['cpu_baseline']['value'], d['gpu_over_cpu'], d['roofline']['traversal_mismatch'])"
 done
