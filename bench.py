@@ -80,6 +80,8 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default=HEADLINE, choices=sorted(WORKLOADS))
     ap.add_argument("--mode", default="tiles", choices=["tiles", "spp"], help="N>1: tile partition + gather, or spp split + accumulator sum")
+    ap.add_argument("--reduce", default="ordered", choices=["ordered", "allreduce"],
+                    help="--mode spp: gather + sum in rank order on rank 0 (deterministic), or one RCCL all-reduce")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle legs (roofline statistics and CPU baseline)")
     ap.add_argument("--no-target-scene", action="store_true", help="do not also time the target scene (configs[2])")
     ap.add_argument("--launcher", action="store_true", help="go through torch.distributed.run even for --gpus 1 (rehearsal of the N > 1 path)")
@@ -133,7 +135,8 @@ def measure(workload, args, ctx):
         s_first, s_count = sample_range_of_rank(spp, rank, n_gpus)
         acc = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
         frame = torch.zeros((H, W, 3), dtype=torch.float32, device=dev) if rank == 0 else None
-        parallelism = f"spp split: {n_gpus} ranks x {s_count} samples + accumulator gather/sum on rank 0"
+        parallelism = (f"spp split: {n_gpus} ranks x {s_count} samples + " +
+                       ("accumulator gather + sum in rank order on rank 0" if args.reduce == "ordered" else "RCCL all-reduce of the accumulators"))
 
     def step():
         if args.mode == "tiles":
@@ -147,7 +150,7 @@ def measure(workload, args, ctx):
             acc.zero_()
             if s_count:
                 scene.accumulate_chunk_device(settings, whole, SEED, s_first, s_count, acc.data_ptr(), counters.data_ptr(), stream)
-            total = reduce_accumulators(acc, rank, n_gpus)
+            total = reduce_accumulators(acc, rank, n_gpus, how=args.reduce)
             if rank == 0:
                 resolve_device(device, total.data_ptr(), W * H, spp, frame.data_ptr(), None, stream)
 

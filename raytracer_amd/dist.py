@@ -145,10 +145,19 @@ class InterleavedCompositor:
         return self.frame
 
 
-def reduce_accumulators(acc, rank, world, dst=0):
-    """Sum the per-rank accumulators onto rank `dst` in rank order (deterministic)."""
+def reduce_accumulators(acc, rank, world, dst=0, how="ordered"):
+    """Sum the per-rank accumulators onto rank `dst`.
+
+    how="ordered"  : gather + add in rank order on `dst`: deterministic, equal bit for bit to a one-GPU frame that forms
+                     its segment sums in the same ranges (the default).
+    how="allreduce": one RCCL all-reduce (BASELINE configs[4] names it): every rank ends with the frame sum; the order of the
+                     additions is the collective's, so the result may differ from the ordered sum in the last ulp."""
     if world == 1:
         return acc
+    if how == "allreduce":
+        total = acc.clone()
+        dist.all_reduce(total, op=dist.ReduceOp.SUM)
+        return total if rank == dst else None
     gathered = [torch.zeros_like(acc) for _ in range(world)] if rank == dst else None
     gathered = _gather(acc, gathered, dst, rank, world)
     if rank != dst:

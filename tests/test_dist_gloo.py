@@ -50,7 +50,9 @@ def _worker(rank, world, port, mode, result_path):
             assert first % sample_segment() == 0
             acc = torch.from_numpy(o.accumulate_chunk(st, whole, SEED, first, count))
             total = reduce_accumulators(acc, rank, world)
+            summed = reduce_accumulators(acc, rank, world, how="allreduce")        # the collective of BASELINE configs[4]
             if rank == 0:
+                assert np.abs(summed.numpy() - total.numpy()).max() <= 1e-5 * SPP      # same sum, the collective's association
                 parts = [o.accumulate_chunk(st, whole, SEED, *sample_range_of_rank(SPP, r, world)) for r in range(world)]
                 expect = parts[0].copy()
                 for p in parts[1:]:
