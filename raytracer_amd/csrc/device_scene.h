@@ -105,6 +105,7 @@ struct DevSceneView {
     uint32_t lds_nodes;           // the first lds_nodes node records are kept in LDS by the render kernel
     const DevNode* nodes;         // the top levels of the TLAS and of every BLAS first (breadth first), then the rest of each tree (depth first)
     const DevEntity* entities;    // TLAS leaf order
+    const Word4* ent_box;         // per entity (TLAS leaf order) its own world box, 2 words: (lo.xyz, -) (hi.xyz, -); Entity::calculate_origin_aabb
     const Word4* xforms;
     const DevMesh* meshes;
     const DevTriHot* tri_hot;

@@ -120,6 +120,9 @@ __device__ __forceinline__ Word4 ldw(const Word4* p) {
 // by the exact (t, rank) order, so a candidate visited needlessly never changes the result; the bound never
 // exceeds the ray's t_max, so no box is entered that the reference's own test would reject.
 #define RT_CULL_SLACK 1.0009765625f
+#ifndef RT_OWN_BOX_PRETEST
+#define RT_OWN_BOX_PRETEST 1
+#endif
 // Sticky device-side error word (host-mapped, RtScene::dev_error): a capacity that the host sized from the trees turned
 // out too small.  Never expected; reported as RT_E_DEPTH instead of a silently wrong image.
 #define RT_DEVERR_STACK   1u      /* traversal stack full: a deferred subtree would have been dropped */
@@ -310,6 +313,16 @@ __device__ __forceinline__ void trace(const DevSceneView& S, const F3 wo, const 
             const Word4* ew = S.entities[ei].w;
             const Word4 e0 = ldw(ew), e1 = ldw(ew + 1);
             const uint32_t kind = e1.u[0] & 0xff;
+            if (!S.loose_boxes && RT_OWN_BOX_PRETEST && kind == RT_HITABLE_MESH) {      // the render kernel's pre-test of the instance's own world box (see there)
+                const Word4 bl = ldw(S.ent_box + 2 * ei), bh = ldw(S.ent_box + 2 * ei + 1);
+                const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
+                const float ax = ((nx ? bh.f[0] : bl.f[0]) - wo.x) * inv.x, bx = ((nx ? bl.f[0] : bh.f[0]) - wo.x) * inv.x;
+                const float ay = ((ny ? bh.f[1] : bl.f[1]) - wo.y) * inv.y, by = ((ny ? bl.f[1] : bh.f[1]) - wo.y) * inv.y;
+                const float az = ((nz ? bh.f[2] : bl.f[2]) - wo.z) * inv.z, bz = ((nz ? bl.f[2] : bh.f[2]) - wo.z) * inv.z;
+                const float tn = fmaxf(fmaxf(fmaxf(ax, ay), az), t_min);
+                const float tf = fminf(fminf(fminf(bx, by), bz), best_t);
+                if (tf * RT_CULL_SLACK < tn) continue;
+            }
             F3 eo = wo, ed = wd;
             ray_to_entity(S, e0, e1, eo, ed);
             float t = 0.0f; bool hit = false;
@@ -638,7 +651,7 @@ enum { PH_NODE = 0, PH_TRI, PH_ENTITY, PH_SHADE, PH_SHADE_PATH_HIT, PH_SHADE_SHA
 // RICH: lamp lights, or textures other than colours and checkers (S.rich_shading);
 // DOF: some primary hit can be out of focus by more than the threshold of the lens-cell rounds (S.coc_rel_max x image
 //   width, decided per launch): without it the second round shape is compiled out (Dreadnaught +3 %).
-template <bool LOOSE, bool MESH, bool SPHERES, bool PLANES, bool XFORMS, bool RICH, bool DOF>
+template <bool LOOSE, bool MESH, bool SPHERES, bool PLANES, bool XFORMS, bool RICH, bool DOF, bool MULTI = false>
 __global__ void __launch_bounds__(RT_BLOCK, RT_WAVES_PER_SIMD)
 render_kernel(const DevSceneView S, const RenderParams P) {
     extern __shared__ uint32_t lds_stack[];
@@ -1109,8 +1122,30 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                             PH(PH_ENTITY);
                             const uint32_t ei = first + k;
                             const Word4* ew = S.entities[ei].w;
+                            // A leaf of the reference holds up to two entities and passes when the UNION of their boxes does; the reference then
+                            // runs Entity::hit on both, and the walk may reach the leaf long after its box was tested (popped from the stack, the best
+                            // hit has moved closer since).  For a mesh instance Entity::hit is the whole ray transform, three divisions and the BLAS root
+                            // test - spared here when the ray, cut at the CURRENT culling bound, misses the instance's OWN world box
+                            // (calculate_origin_aabb: it contains the rotated mesh box, hence every hit Entity::hit could report) by more than
+                            // RT_CULL_SLACK.  `inv` is the world ray's here (a lane at a TLAS leaf is never inside an instance).  900 instances +16 %,
+                            // mesh_demo +5 %.  In mesh-only scenes the test comes before the entity record is even fetched.  MULTI: the scene has mesh
+                            // instances AND more than one entity; a lone entity's box is the root box, and merely compiling the test in costs that
+                            // instantiation 1-6 % (register allocation), so single-entity scenes (Dreadnaught) run instantiations without it.
+                            auto misses_own_box = [&]() -> bool {
+                                const Word4 bl = ldw(S.ent_box + 2 * ei), bh = ldw(S.ent_box + 2 * ei + 1);
+                                const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
+                                const float ax = ((nx ? bh.f[0] : bl.f[0]) - wo.x) * inv.x, bx = ((nx ? bl.f[0] : bh.f[0]) - wo.x) * inv.x;
+                                const float ay = ((ny ? bh.f[1] : bl.f[1]) - wo.y) * inv.y, by = ((ny ? bl.f[1] : bh.f[1]) - wo.y) * inv.y;
+                                const float az = ((nz ? bh.f[2] : bl.f[2]) - wo.z) * inv.z, bz = ((nz ? bl.f[2] : bh.f[2]) - wo.z) * inv.z;
+                                const float tn = fmaxf(fmaxf(fmaxf(ax, ay), az), t_min);
+                                const float tf = fminf(fminf(fminf(bx, by), bz), best_t);
+                                return tf * RT_CULL_SLACK < tn;
+                            };
+                            constexpr bool MESH_ONLY = MESH && !SPHERES && !PLANES;
+                            if (MULTI && MESH_ONLY && !LOOSE && RT_OWN_BOX_PRETEST && misses_own_box()) continue;
                             const Word4 e0 = ldw(ew), e1 = ldw(ew + 1);
                             const uint32_t kind = e1.u[0] & 0xff;
+                            if (MULTI && MESH && !MESH_ONLY && !LOOSE && RT_OWN_BOX_PRETEST && kind == RT_HITABLE_MESH && misses_own_box()) continue;
                             F3 eo = wo, ed = wd;
                             ray_to_entity<XFORMS>(S, e0, e1, eo, ed);
                             float t = 0.0f; bool hit = false;
@@ -1747,6 +1782,14 @@ int enqueue_accumulate(RtScene* scene, Workspace& ws, const RtSettings* st, cons
                                                RT_K8(false, false, true),  RT_K8(true, false, true),  RT_K8(false, true, true),  RT_K8(true, true, true)};
 #undef RT_K8
 #undef RT_K
+            // the same table for scenes with mesh instances and more than one entity (MULTI: own-box pre-test of instances); only the mesh columns exist
+#define RT_K(M, S_, P_, X, R, D) render_kernel<false, M, S_, P_, X, R, D, true>
+#define RT_K8(X, R, D) nullptr, RT_K(true, false, false, X, R, D), nullptr, RT_K(true, true, false, X, R, D), \
+                       nullptr, RT_K(true, false, true, X, R, D), nullptr, RT_K(true, true, true, X, R, D)
+            static const Kernel kernels_multi[64] = {RT_K8(false, false, false), RT_K8(true, false, false), RT_K8(false, true, false), RT_K8(true, true, false),
+                                                     RT_K8(false, false, true),  RT_K8(true, false, true),  RT_K8(false, true, true),  RT_K8(true, true, true)};
+#undef RT_K8
+#undef RT_K
             const DevSceneView& v = view;
             const bool dof = v.coc_rel_max * (float)st->width > P.lens_coc_px;       // (inf x width = inf: unbounded scenes keep both round shapes)
             int which = (v.mesh_entities ? 1 : 0) | (v.sphere_entities ? 2 : 0) | (v.plane_entities ? 4 : 0) | (v.general_xforms ? 8 : 0) | (v.rich_shading ? 16 : 0) |
@@ -1754,7 +1797,8 @@ int enqueue_accumulate(RtScene* scene, Workspace& ws, const RtSettings* st, cons
             if ((which & 7) == 0) which |= 2;                                        // (an empty scene: any instantiation will do)
             static const bool show_traits = getenv("RT_DEBUG_TRAITS") != nullptr;      // diagnostics: which instantiation a scene runs
             if (show_traits) fprintf(stderr, "traits: which=%d loose=%u any_hit=%u lds_nodes=%u\n", which, v.loose_boxes, v.shadow_any_hit, v.lds_nodes);
-            const Kernel kernel = v.loose_boxes ? render_kernel<true, true, true, true, true, true, true> : kernels[which];
+            const bool multi = v.mesh_entities && v.entity_count > 1u;
+            const Kernel kernel = v.loose_boxes ? render_kernel<true, true, true, true, true, true, true> : (multi ? kernels_multi[which] : kernels[which]);
             hipLaunchKernelGGL(kernel, dim3((uint32_t)blocks), dim3(RT_BLOCK), scene->lds_bytes, stream, view, P);
         }
         HIP_TRY(hipGetLastError());
@@ -1830,11 +1874,8 @@ RtScene* rt_scene_create(const RtSceneDesc* desc, int device) {
     s->refit_level_start = std::move(flat.refit_level_start);
     if (flat.refit.empty()) flat.refit.emplace_back();
     if (upload(s, flat.refit, &s->refit_dev)) return fail();
-    {
-        void* p = nullptr;
-        if (hipMalloc(&p, ((size_t)desc->entity_count + 1) * 8 * sizeof(float)) != hipSuccess) { set_error(RT_E_HIP, "hipMalloc (entity boxes) failed"); return fail(); }
-        s->allocations.push_back(p); s->ent_box_dev = (float*)p;
-    }
+    if (upload(s, flat.ent_box, &s->view.ent_box)) return fail();      // the build's entity boxes; rt_scene_update_transforms recomputes them in place
+    s->ent_box_dev = reinterpret_cast<float*>(const_cast<Word4*>(s->view.ent_box));
     if (upload(s, flat.nodes, &s->view.nodes) || upload(s, flat.entities, &s->view.entities) || upload(s, flat.xforms, &s->view.xforms) ||
         upload(s, flat.meshes, &s->view.meshes) || upload(s, flat.tri_hot, &s->view.tri_hot) || upload(s, flat.tri_cold, &s->view.tri_cold) ||
         upload(s, flat.tri_rank, &s->view.tri_rank) || upload(s, flat.planes, &s->view.planes) || upload(s, flat.materials, &s->view.materials) ||

@@ -670,6 +670,12 @@ int build_flat_scene(const RtSceneDesc* d, FlatScene& out, std::string& err) {
     for (uint32_t k = 0; k < pos_order.size(); k++) { erank[pos_order[k]] = k; out.tlas_order[k] = tlas.perm[pos_order[k]]; }
     out.entities.resize(n_ent);
     out.tlas_perm = tlas.perm;
+    out.ent_box.resize((n_ent + 1) * 2);
+    for (uint64_t p = 0; p < n_ent; p++) {
+        const Box& bx = ebox[tlas.perm[p]];
+        Word4 lo, hi; lo.f[0] = bx.lo.x; lo.f[1] = bx.lo.y; lo.f[2] = bx.lo.z; lo.f[3] = 0.0f; hi.f[0] = bx.hi.x; hi.f[1] = bx.hi.y; hi.f[2] = bx.hi.z; hi.f[3] = 0.0f;
+        out.ent_box[2 * p] = lo; out.ent_box[2 * p + 1] = hi;
+    }
     uint64_t inst_tris = 0;
     uint32_t xform_at = 0;
     for (uint64_t p = 0; p < n_ent; p++) {

@@ -18,6 +18,7 @@ struct RefitRec { uint32_t node, l_first, l_count, l_child, r_first, r_count, r_
 struct FlatScene {
     std::vector<DevNode> nodes;
     std::vector<DevEntity> entities;
+    std::vector<Word4> ent_box;          // 2 words per entity, TLAS leaf order (+ 2 spare words: the root box of a refit)
     std::vector<Word4> xforms;
     std::vector<DevMesh> meshes;
     std::vector<DevTriHot> tri_hot;
