@@ -203,8 +203,16 @@ __device__ __forceinline__ void slab2(const Word4& a, const Word4& b, const Word
     hr = slab(a.f[1], a.f[3], b.f[1], b.f[3], c.f[1], c.f[3], o, inv, t_min, t_max, er);
 }
 
+// Record `index` of an array of `stride`-byte records through a 32-bit byte offset from the (wave-uniform) base: the load then takes
+// its address as SGPR base + VGPR offset, where base[index] costs a 64-bit multiply-add per lane (quarter rate).  rt_scene_create
+// refuses scenes whose arrays exceed 4 GiB.  (Dreadnaught +1 %, mesh_demo +1.3 %, 900 instances +1.6 % for the node records alone.)
+template <class T>
+__device__ __forceinline__ const Word4* rec32(const T* base, uint32_t index, uint32_t stride) {
+    return reinterpret_cast<const Word4*>(reinterpret_cast<const char*>(base) + index * stride);
+}
+
 // reference visit rank of the entity at TLAS position `ei`: decides exact ties in t between two entities (implementation.rs:415)
-__device__ __forceinline__ uint32_t entity_rank(const DevSceneView& S, uint32_t ei) { return ldw(S.entities[ei].w + 2).u[3]; }
+__device__ __forceinline__ uint32_t entity_rank(const DevSceneView& S, uint32_t ei) { return ldw(rec32(S.entities, ei, (uint32_t)sizeof(DevEntity)) + 2).u[3]; }
 
 // Entity::hit's world -> entity ray transform, implementation.rs:288-294
 // XFORMS = false: every entity of the scene has exactly one translation and no rotation
@@ -1059,7 +1067,8 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                         na.f[0] = v0.x; na.f[1] = v0.y; na.f[2] = v0.z; na.f[3] = v0.w; nb.f[0] = v1.x; nb.f[1] = v1.y; nb.f[2] = v1.z; nb.f[3] = v1.w;
                         nc.f[0] = v2.x; nc.f[1] = v2.y; nc.f[2] = v2.z; nc.f[3] = v2.w; nr.f[0] = v3.x; nr.f[1] = v3.y; nr.f[2] = v3.z; nr.f[3] = v3.w;
                     } else {
-                        const Word4* n = S.nodes[cur].w;
+                        // (32-bit byte offset from the uniform base: one shift instead of a 64-bit shift and add; rt_scene_create refuses scenes of 2^26 records)
+                        const Word4* n = reinterpret_cast<const Word4*>(reinterpret_cast<const char*>(S.nodes) + (cur << 6));
                         na = ldw(n); nb = ldw(n + 1); nc = ldw(n + 2); nr = ldw(n + 3);
                     }
                     float el, er; bool hl, hr;
@@ -1084,7 +1093,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                         for (uint32_t k = 0; k < count; k++) {
                             PH(PH_TRI);
                             const uint32_t ti = tri_base + first + k;
-                            const Word4* tw = S.tri_hot[ti].w;
+                            const Word4* tw = rec32(S.tri_hot, ti, (uint32_t)sizeof(DevTriHot));
                             const Word4 ta = ldw(tw), tb = ldw(tw + 1), tc = ldw(tw + 2);
                             const F3 A = w3(ta), B = w3(tb), C = w3(tc), normal = f3(ta.f[3], tb.f[3], tc.f[3]);
                             const float denominator = dot(d, normal);                       // plane.rs:7-10
@@ -1121,7 +1130,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                         for (uint32_t k = 0; k < count && !entered; k++) {
                             PH(PH_ENTITY);
                             const uint32_t ei = first + k;
-                            const Word4* ew = S.entities[ei].w;
+                            const Word4* ew = rec32(S.entities, ei, (uint32_t)sizeof(DevEntity));
                             // A leaf of the reference holds up to two entities and passes when the UNION of their boxes does; the reference then
                             // runs Entity::hit on both, and the walk may reach the leaf long after its box was tested (popped from the stack, the best
                             // hit has moved closer since).  For a mesh instance Entity::hit is the whole ray transform, three divisions and the BLAS root
@@ -1132,7 +1141,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                             // instances AND more than one entity; a lone entity's box is the root box, and merely compiling the test in costs that
                             // instantiation 1-6 % (register allocation), so single-entity scenes (Dreadnaught) run instantiations without it.
                             auto misses_own_box = [&]() -> bool {
-                                const Word4 bl = ldw(S.ent_box + 2 * ei), bh = ldw(S.ent_box + 2 * ei + 1);
+                                const Word4 bl = ldw(rec32(S.ent_box, ei, 32u)), bh = ldw(rec32(S.ent_box, ei, 32u) + 1);
                                 const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
                                 const float ax = ((nx ? bh.f[0] : bl.f[0]) - wo.x) * inv.x, bx = ((nx ? bl.f[0] : bh.f[0]) - wo.x) * inv.x;
                                 const float ay = ((ny ? bh.f[1] : bl.f[1]) - wo.y) * inv.y, by = ((ny ? bl.f[1] : bh.f[1]) - wo.y) * inv.y;
@@ -1176,7 +1185,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                                 }
                             } else if (MESH) {
                                 // MeshObject::hit -> BLAS (mesh.rs:161-176): enter the instance
-                                const Word4* mw = S.meshes[e1.u[1]].w;
+                                const Word4* mw = rec32(S.meshes, e1.u[1], (uint32_t)sizeof(DevMesh));
                                 const Word4 m0 = ldw(mw), m1 = ldw(mw + 1), m2 = ldw(mw + 2);
                                 const F3 einv = f3(1.0f / ed.x, 1.0f / ed.y, 1.0f / ed.z);
                                 float e;
@@ -1876,6 +1885,9 @@ RtScene* rt_scene_create(const RtSceneDesc* desc, int device) {
     if (upload(s, flat.refit, &s->refit_dev)) return fail();
     if (upload(s, flat.ent_box, &s->view.ent_box)) return fail();      // the build's entity boxes; rt_scene_update_transforms recomputes them in place
     s->ent_box_dev = reinterpret_cast<float*>(const_cast<Word4*>(s->view.ent_box));
+    if (flat.nodes.size() >= ((size_t)1 << 26) || flat.tri_hot.size() >= ((size_t)1 << 26) || flat.entities.size() >= ((size_t)1 << 26)) {
+        set_error(RT_E_LIMIT, "more than 2^26 tree records, triangles or entities (the walk addresses them by 32-bit byte offsets)"); return fail();
+    }
     if (upload(s, flat.nodes, &s->view.nodes) || upload(s, flat.entities, &s->view.entities) || upload(s, flat.xforms, &s->view.xforms) ||
         upload(s, flat.meshes, &s->view.meshes) || upload(s, flat.tri_hot, &s->view.tri_hot) || upload(s, flat.tri_cold, &s->view.tri_cold) ||
         upload(s, flat.tri_rank, &s->view.tri_rank) || upload(s, flat.planes, &s->view.planes) || upload(s, flat.materials, &s->view.materials) ||
