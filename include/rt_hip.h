@@ -228,7 +228,8 @@ const char* rt_last_error(void);
  * (mesh.rs:84-90): validates the description, builds the TLAS over entities and
  * one BLAS per mesh with the reference's algorithm (bvh.rs:129-188,
  * util.rs:6-28), flattens everything and uploads it to `device`.
- * Returns NULL on failure. */
+ * Returns NULL on failure.  Limits (RT_E_LIMIT): fewer than 2^26 tree records, 2^26 triangles (distinct, not
+ * instanced) and 2^26 entities - the kernels address them through 32-bit byte offsets. */
 RtScene* rt_scene_create(const RtSceneDesc* desc, int device);
 /* device == RT_DEVICE_HOST_ONLY: validate and build the acceleration structures
  * but upload nothing; such a scene only serves rt_scene_info / rt_scene_bvh_order
