@@ -248,6 +248,18 @@ void     rt_scene_destroy(RtScene* scene);
  * No render call on this scene may be in flight. */
 int rt_scene_update_transforms(RtScene* scene, const RtV3* translations, uint64_t translation_count,
                                const RtRotation* rotations, uint64_t rotation_count, void* stream);
+/* The same call, but with a NEW top-level tree: a linear BVH over the Morton codes of the moved entities' box centres, built
+ * on the device (raytracer_amd/csrc/tlas_build.h; the reference's Scene::build_bvh, implementation.rs:377-383 over
+ * bvh.rs:129-188, is a CPU mean-split build per frame).  For animations in which entities travel: a refitted tree keeps
+ * the grouping of the first frame and degrades.  The tree differs from the reference's, so candidates are pruned by other
+ * boxes: the nearest hit is the reference's except where a ray grazes the boundary of an entity's own box (f32 rounding),
+ * exact ties keep the reference's visit ranks.  After this call rt_scene_update_transforms is refused (its tables describe
+ * the replaced tree) and rt_scene_bvh_order(-1) still reports the tree of rt_scene_create.  The first call allocates
+ * (about 150 bytes per entity + 64 per entity of node records).  Enqueued on `stream`, then waits for it.  No render call
+ * on this scene may be in flight.  RT_E_DEPTH: the new tree is deeper than the LDS traversal stack can hold (64 levels);
+ * the scene must then be created anew. */
+int rt_scene_rebuild_tlas(RtScene* scene, const RtV3* translations, uint64_t translation_count,
+                          const RtRotation* rotations, uint64_t rotation_count, void* stream);
 
 /* Switches of the sampler and of the launch schedule of one scene (no reference counterpart except
  * RT_OPT_LENS_SAMPLER 0).  Takes effect for calls that start afterwards.  Defaults can be preset through the

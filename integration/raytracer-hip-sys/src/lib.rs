@@ -263,6 +263,7 @@ extern "C" {
     pub fn rt_scene_create(desc: *const RtSceneDesc, device: c_int) -> *mut RtScene;
     pub fn rt_scene_destroy(scene: *mut RtScene);
     pub fn rt_scene_update_transforms(scene: *mut RtScene, translations: *const RtV3, translation_count: u64, rotations: *const RtRotation, rotation_count: u64, stream: *mut c_void) -> c_int;
+    pub fn rt_scene_rebuild_tlas(scene: *mut RtScene, translations: *const RtV3, translation_count: u64, rotations: *const RtRotation, rotation_count: u64, stream: *mut c_void) -> c_int;
     pub fn rt_scene_set_option(scene: *mut RtScene, option: u32, value: f64) -> c_int;
     pub fn rt_render_chunk(scene: *mut RtScene, settings: *const RtSettings, chunk: *const RtRenderChunk, seed: u64, rgb_out: *mut f32, rgba_out: *mut u8, counters: *mut RtRayCounters) -> c_int;
     pub fn rt_render_chunk_device(scene: *mut RtScene, settings: *const RtSettings, chunk: *const RtRenderChunk, seed: u64, rgb_dev: *mut c_void, rgba_dev: *mut c_void, pitch_pixels: u32, out_x: u32, out_y: u32, counters_dev: *mut c_void, stream: *mut c_void) -> c_int;

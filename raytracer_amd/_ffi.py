@@ -178,6 +178,7 @@ HIP_PROTOTYPES = {
     "rt_scene_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "rt_scene_set_option": (C.c_int, [C.c_void_p, C.c_uint32, C.c_double]),
     "rt_scene_update_transforms": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p]),
+    "rt_scene_rebuild_tlas": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p]),
     "rt_scene_profile_read": (C.c_int, [C.c_void_p, _P(C.c_double), _P(C.c_uint64)]),
 }
 

@@ -23,6 +23,7 @@
 //     the image is independent of chunking, launch shape and GPU count.
 // MFMA is deliberately unused: nothing here is a dense contraction.
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>      // rocPRIM's device radix sort (rt_scene_rebuild_tlas)
 
 #include <cmath>
 #include <cstdio>
@@ -1482,6 +1483,8 @@ __global__ void refit_root_kernel(const DevNode* nodes, uint32_t root_ref, uint3
     root_box[0] = lo.x; root_box[1] = lo.y; root_box[2] = lo.z; root_box[3] = hi.x; root_box[4] = hi.y; root_box[5] = hi.z;
 }
 
+#include "tlas_build.h"      // device-side BUILD of the TLAS (rt_scene_rebuild_tlas)
+
 // ===========================================================================
 // host side
 // ===========================================================================
@@ -1594,6 +1597,20 @@ struct RtScene {
     std::vector<uint32_t> refit_level_start;
     const RefitRec* refit_dev = nullptr;
     float* ent_box_dev = nullptr;           // 8 floats per entity + 8 for the root box
+    bool refit_valid = true;                // false once rt_scene_rebuild_tlas has replaced the topology the refit tables describe
+    // rt_scene_rebuild_tlas: sizes of the build, and the buffers of the device-side build (allocated by its first call)
+    size_t node_count = 0;                  // records of the scene as built: the rebuilt TLAS's records are appended behind them
+    uint32_t tlas_hot_records = 0, blas_walk_depth = 0, lds_nodes_built = 0;
+    struct TlasRebuild {
+        bool ready = false;
+        unsigned long long *keys_a = nullptr, *keys_b = nullptr;
+        void* sort_temp = nullptr; size_t sort_temp_bytes = 0;
+        LbvhNode* lnodes = nullptr;
+        uint32_t *parent = nullptr, *height = nullptr, *arrived = nullptr, *number = nullptr, *queue = nullptr;
+        float *box = nullptr, *bounds = nullptr;
+        DevEntity* entities_alt = nullptr;
+        float* ent_box_alt = nullptr;
+    } rebuild;
     // Device-pointer entry points run on the CALLER's stream and share this workspace:
     // `lock` serialises their enqueueing, the caller keeps them on one stream.
     std::mutex lock;
@@ -1881,6 +1898,7 @@ RtScene* rt_scene_create(const RtSceneDesc* desc, int device) {
     s->n_translations = desc->translation_count; s->n_rotations = desc->rotation_count;
     s->xforms_words = flat.xforms.size();
     s->refit_level_start = std::move(flat.refit_level_start);
+    s->node_count = flat.nodes.size(); s->tlas_hot_records = flat.tlas_hot_records; s->blas_walk_depth = flat.blas_walk_depth; s->lds_nodes_built = flat.view.lds_nodes;
     if (flat.refit.empty()) flat.refit.emplace_back();
     if (upload(s, flat.refit, &s->refit_dev)) return fail();
     if (upload(s, flat.ent_box, &s->view.ent_box)) return fail();      // the build's entity boxes; rt_scene_update_transforms recomputes them in place
@@ -2040,6 +2058,7 @@ int rt_scene_update_transforms(RtScene* scene, const RtV3* translations, uint64_
     if (scene->device == RT_DEVICE_HOST_ONLY) return set_error(RT_E_NO_DEVICE, "scene was created host-only");
     if (translation_count != scene->n_translations || rotation_count != scene->n_rotations)
         return set_error(RT_E_INVALID, "rt_scene_update_transforms: the arrays must have the sizes given to rt_scene_create (entities keep their ranges)");
+    if (!scene->refit_valid) return set_error(RT_E_INVALID, "rt_scene_update_transforms: the tree was rebuilt on the device (rt_scene_rebuild_tlas); its refit tables are gone - rebuild again");
     if ((translation_count && !translations) || (rotation_count && !rotations)) return set_error(RT_E_INVALID, "null transform array");
     std::lock_guard<std::mutex> g(scene->lock);
     HIP_TRY(hipSetDevice(scene->device));
@@ -2071,6 +2090,119 @@ int rt_scene_update_transforms(RtScene* scene, const RtV3* translations, uint64_
     for (int k = 0; k < 3; k++) { scene->view.tlas_min[k] = root[k]; scene->view.tlas_max[k] = root[3 + k]; }
     scene->view.loose_boxes = loose ? 1u : 0u;
     scene->view.coc_rel_max = host_coc_rel_max(scene->camera, scene->view.tlas_min, scene->view.tlas_max, n > 0);
+    return RT_OK;
+}
+
+// A NEW top-level tree over the moved entities, built on the device (tlas_build.h).
+int rt_scene_rebuild_tlas(RtScene* scene, const RtV3* translations, uint64_t translation_count, const RtRotation* rotations,
+                          uint64_t rotation_count, void* stream) {
+    if (!scene) return set_error(RT_E_INVALID, "null scene");
+    if (scene->device == RT_DEVICE_HOST_ONLY) return set_error(RT_E_NO_DEVICE, "scene was created host-only");
+    if (translation_count != scene->n_translations || rotation_count != scene->n_rotations)
+        return set_error(RT_E_INVALID, "rt_scene_rebuild_tlas: the arrays must have the sizes given to rt_scene_create (entities keep their ranges)");
+    if ((translation_count && !translations) || (rotation_count && !rotations)) return set_error(RT_E_INVALID, "null transform array");
+    std::lock_guard<std::mutex> g(scene->lock);
+    HIP_TRY(hipSetDevice(scene->device));
+    hipStream_t sm = (hipStream_t)stream;
+    const uint32_t n = scene->view.entity_count;
+    RtScene::TlasRebuild& rb = scene->rebuild;
+    if (!rb.ready) {
+        // first call: the build's buffers (about 150 bytes per entity) and a node array with room for n - 1 more records
+        auto dev_alloc = [&](void** p, size_t bytes) -> int {
+            HIP_TRY(hipMalloc(p, bytes ? bytes : 16));
+            scene->allocations.push_back(*p);
+            return RT_OK;
+        };
+        const size_t m = n > 1 ? n - 1 : 1;
+        int rc;
+        if ((rc = dev_alloc((void**)&rb.keys_a, (size_t)(n + 1) * 8)) || (rc = dev_alloc((void**)&rb.keys_b, (size_t)(n + 1) * 8)) ||
+            (rc = dev_alloc((void**)&rb.lnodes, m * sizeof(LbvhNode))) || (rc = dev_alloc((void**)&rb.parent, (size_t)(2 * (size_t)n + 1) * 4)) ||
+            (rc = dev_alloc((void**)&rb.height, m * 4)) || (rc = dev_alloc((void**)&rb.arrived, m * 4)) || (rc = dev_alloc((void**)&rb.number, m * 4)) ||
+            (rc = dev_alloc((void**)&rb.queue, ((size_t)scene->tlas_hot_records + 1) * 4)) || (rc = dev_alloc((void**)&rb.box, m * 32)) ||
+            (rc = dev_alloc((void**)&rb.bounds, 64)) || (rc = dev_alloc((void**)&rb.entities_alt, (size_t)(n + 1) * sizeof(DevEntity))) ||
+            (rc = dev_alloc((void**)&rb.ent_box_alt, ((size_t)n + 1) * 32)))
+            return rc;
+        rb.sort_temp_bytes = 0;
+        HIP_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, rb.sort_temp_bytes, rb.keys_a, rb.keys_b, (int)n, 0, 62, sm));
+        if ((rc = dev_alloc(&rb.sort_temp, rb.sort_temp_bytes))) return rc;
+        DevNode* bigger = nullptr;
+        if ((rc = dev_alloc((void**)&bigger, (scene->node_count + m) * sizeof(DevNode)))) return rc;
+        HIP_TRY(hipMemcpyAsync(bigger, scene->view.nodes, scene->node_count * sizeof(DevNode), hipMemcpyDeviceToDevice, sm));
+        HIP_TRY(hipStreamSynchronize(sm));
+        scene->view.nodes = bigger;           // (the old array stays allocated until the scene is destroyed: launches in flight may still read it)
+        rb.ready = true;
+    }
+    // host: transform records, as in rt_scene_update_transforms
+    bool loose = false;
+    host_make_xforms(scene->desc_entities.data(), scene->tlas_perm, translations, rotations, scene->xforms_host, loose);
+    if (scene->xforms_host.size() != scene->xforms_words) return set_error(RT_E_INVALID, "rt_scene_rebuild_tlas: internal size mismatch");
+    Word4* xforms_dev = const_cast<Word4*>(scene->view.xforms);
+    DevNode* nodes_dev = const_cast<DevNode*>(scene->view.nodes);
+    DevEntity* ent_cur = const_cast<DevEntity*>(scene->view.entities);
+    float* box_cur = scene->ent_box_dev;
+    HIP_TRY(hipMemcpyAsync(xforms_dev, scene->xforms_host.data(), scene->xforms_host.size() * sizeof(Word4), hipMemcpyHostToDevice, sm));
+    scene->refit_valid = false;               // from here on the old tree no longer matches the entity boxes
+    uint32_t root_ref = RT_REF_LEAF_BIT;      // (n == 0: never followed, the root box is empty)
+    const uint32_t hot = scene->tlas_hot_records, append_base = (uint32_t)scene->node_count;
+    uint32_t height0 = 0;
+    if (n > 0) {
+        const dim3 blk(256), per_entity((n + 255) / 256);
+        hipLaunchKernelGGL(refit_entities_kernel, per_entity, blk, 0, sm, ent_cur, (const Word4*)xforms_dev, scene->view.meshes, box_cur, n);
+        hipLaunchKernelGGL(lbvh_bounds_kernel, dim3(1), blk, 0, sm, (const float*)box_cur, n, rb.bounds);
+        hipLaunchKernelGGL(lbvh_keys_kernel, per_entity, blk, 0, sm, (const float*)box_cur, n, (const float*)rb.bounds, rb.keys_a);
+        HIP_TRY_SYNC(hipGetLastError(), sm);
+        size_t temp_bytes = rb.sort_temp_bytes;
+        HIP_TRY_SYNC(hipcub::DeviceRadixSort::SortKeys(rb.sort_temp, temp_bytes, rb.keys_a, rb.keys_b, (int)n, 0, 62, sm), sm);
+        hipLaunchKernelGGL(lbvh_permute_kernel, per_entity, blk, 0, sm, (const unsigned long long*)rb.keys_b, n, (const DevEntity*)ent_cur, rb.entities_alt,
+                           (const float*)box_cur, rb.ent_box_alt, (uint32_t*)nullptr);
+        std::swap(ent_cur, rb.entities_alt); std::swap(box_cur, rb.ent_box_alt);
+        root_ref = RT_REF_LEAF_BIT | ((n - 1u) << RT_REF_COUNT_SHIFT);      // all entities in one leaf ...
+        if (n > RT_LBVH_LEAF) {                                               // ... or a tree
+            const dim3 per_inner((n - 1 + 255) / 256);
+            HIP_TRY_SYNC(hipMemsetAsync(rb.arrived, 0, (size_t)(n - 1) * 4, sm), sm);
+            hipLaunchKernelGGL(lbvh_topology_kernel, per_inner, blk, 0, sm, (const unsigned long long*)rb.keys_b, n, rb.lnodes, rb.parent);
+            hipLaunchKernelGGL(lbvh_boxes_kernel, per_entity, blk, 0, sm, (const LbvhNode*)rb.lnodes, (const uint32_t*)rb.parent, n, (const float*)box_cur, rb.box,
+                               rb.height, rb.arrived);
+            hipLaunchKernelGGL(lbvh_number_init_kernel, per_inner, blk, 0, sm, rb.number, n - 1, append_base);
+            hipLaunchKernelGGL(lbvh_number_kernel, dim3(1), dim3(64), 0, sm, (const LbvhNode*)rb.lnodes, n, hot, rb.number, rb.queue);
+            hipLaunchKernelGGL(lbvh_emit_kernel, per_inner, blk, 0, sm, (const LbvhNode*)rb.lnodes, n, (const uint32_t*)rb.number, (const float*)rb.box,
+                               (const float*)box_cur, nodes_dev);
+            HIP_TRY_SYNC(hipGetLastError(), sm);
+            root_ref = hot > 0 ? 0u : append_base;      // (lbvh_number_kernel: the root is the first record in breadth-first order)
+            HIP_TRY_SYNC(hipMemcpyAsync(&height0, rb.height, 4, hipMemcpyDeviceToHost, sm), sm);
+        }
+    }
+    float* root_dev = box_cur + (size_t)n * 8;
+    hipLaunchKernelGGL(refit_root_kernel, dim3(1), dim3(1), 0, sm, (const DevNode*)nodes_dev, root_ref, n, (const float*)box_cur, root_dev);
+    HIP_TRY_SYNC(hipGetLastError(), sm);
+    float root[6];
+    HIP_TRY_SYNC(hipMemcpyAsync(root, root_dev, sizeof(root), hipMemcpyDeviceToHost, sm), sm);
+    HIP_TRY(hipStreamSynchronize(sm));
+    // the scene now IS the new tree (entity arrays in key order, TLAS cache slots and appended records rewritten)
+    rb.entities_alt = const_cast<DevEntity*>(scene->view.entities) == ent_cur ? rb.entities_alt : const_cast<DevEntity*>(scene->view.entities);
+    scene->view.entities = ent_cur;
+    scene->view.ent_box = reinterpret_cast<const Word4*>(box_cur);
+    scene->ent_box_dev = box_cur;
+    scene->view.tlas_root_ref = root_ref;
+    for (int k = 0; k < 3; k++) { scene->view.tlas_min[k] = root[k]; scene->view.tlas_max[k] = root[3 + k]; }
+    scene->view.loose_boxes = loose ? 1u : 0u;
+    scene->view.coc_rel_max = host_coc_rel_max(scene->camera, scene->view.tlas_min, scene->view.tlas_max, n > 0);
+    // traversal stack for the new depth (scene_build.cpp's bound), and what that leaves the node cache
+    scene->view.stack_entries = height0 + 1u + scene->blas_walk_depth + 2u;
+    const size_t stack_bytes = ((size_t)scene->view.stack_entries + (scene->view.mesh_entities ? 3 : 0)) * RT_BLOCK * sizeof(uint32_t);
+    const size_t block_budget = (size_t)160 * 1024 * RT_BLOCK / (256 * RT_WAVES_PER_SIMD);
+    const size_t room = stack_bytes < block_budget ? (block_budget - stack_bytes) / RT_NODE_CACHE_STRIDE : 0;
+    scene->view.lds_nodes = (uint32_t)std::min<size_t>(scene->lds_nodes_built, room);
+    scene->stack_lds_bytes = stack_bytes;
+    scene->lds_bytes = stack_bytes + (size_t)scene->view.lds_nodes * RT_NODE_CACHE_STRIDE;
+    scene->info.tlas_depth = height0;
+    if (stack_bytes > 64 * 1024)
+        return set_error(RT_E_DEPTH, "rt_scene_rebuild_tlas: the tree over these entities is too deep for the LDS traversal stack (more than 64 levels); create the scene anew");
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_kernel<true, true, true, true, true, true, true>, RT_BLOCK, scene->lds_bytes) == hipSuccess && per_cu >= 1) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, scene->device) == hipSuccess) scene->grid_blocks = prop.multiProcessorCount * per_cu;
+    }
     return RT_OK;
 }
 

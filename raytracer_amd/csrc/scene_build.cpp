@@ -655,6 +655,8 @@ int build_flat_scene(const RtSceneDesc* d, FlatScene& out, std::string& err) {
             emitters[k].reset();
         }
         v.lds_nodes = (uint32_t)n_hot;
+        out.tlas_hot_records = hot.empty() ? 0u : hot[0];
+        out.blas_walk_depth = blas_walk_depth;
     }
     out.info.blas_node_count = out.nodes.size() - out.info.tlas_node_count;
     out.info.blas_depth = blas_depth;

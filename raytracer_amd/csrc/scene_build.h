@@ -40,6 +40,9 @@ struct FlatScene {
     std::vector<RefitRec> refit;
     std::vector<uint32_t> refit_level_start;   // boundaries of the levels in `refit` (deepest first)
     std::vector<uint32_t> tlas_perm;           // TLAS position -> entity index of the description
+    // rebuild of the TLAS on the device (rt_scene_rebuild_tlas): the TLAS's share of the LDS node cache (its records [0, tlas_hot_records)),
+    // and the deepest BLAS walk (the traversal stack bound is tlas depth + 1 + blas_walk_depth + 2)
+    uint32_t tlas_hot_records = 0, blas_walk_depth = 0;
 };
 
 // Host half of rt_scene_update_transforms: the transform records of every entity (layout of FlatScene::xforms) for new

@@ -282,6 +282,13 @@ class Scene:
         self._check(self._lib.rt_scene_update_transforms(self._h, C.cast(d.translations, C.c_void_p), d.translation_count,
                                                          C.cast(d.rotations, C.c_void_p), d.rotation_count, stream))
 
+    def rebuild_tlas(self, builder, stream=None):
+        """rt_scene_rebuild_tlas: like update_transforms, but with a NEW top-level tree built on the device (a linear BVH over
+        the moved entities), for animations in which the entities travel."""
+        d = builder.desc().contents
+        self._check(self._lib.rt_scene_rebuild_tlas(self._h, C.cast(d.translations, C.c_void_p), d.translation_count,
+                                                    C.cast(d.rotations, C.c_void_p), d.rotation_count, stream))
+
     def info(self):
         out = RtSceneInfo()
         self._check(self._lib.rt_scene_info(self._h, C.byref(out)))

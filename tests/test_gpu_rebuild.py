@@ -1,0 +1,144 @@
+"""SURVEY.md 8 f4, the other half: rt_scene_rebuild_tlas moves the entities of an existing scene and BUILDS a new top-level
+tree over them on the device (a linear BVH over Morton codes: raytracer_amd/csrc/tlas_build.h).  The tree is not the
+reference's, so this is the nearest-hit gate, not the bit-exact one: t / normal / ids must be those of a fresh
+rt_scene_create of the moved scene (= the reference's trees) and of the oracle, except where a ray grazes the boundary of an
+entity's own box - none observed on these scenes, bound 1e-4 of the pixels, and there t may only differ by 1e-5 relative."""
+import time
+
+import numpy as np
+import pytest
+
+from raytracer_amd import CameraConfiguration, RenderChunk, RenderSettings, RtError, Scene, SceneBuilder, _ffi, camera_new
+from tests.oracle import OracleScene
+from tests.test_gpu_refit import random_instances
+
+pytestmark = pytest.mark.gpu
+
+
+def nearest_hit_gate(got, want, what):
+    """t, normal, entity, triangle: equal bit for bit on all but 1e-4 of the pixels; there the same t to 1e-5."""
+    t, n, e = got[0], got[1], got[2]
+    wt, wn, we = want[0], want[1], want[2]
+    differ = (e != we) | (t != wt) | np.any(n != wn, axis=-1)
+    frac = float(differ.mean())
+    assert frac <= 1e-4, (what, frac)
+    if differ.any():
+        hit = differ & (e >= 0) & (we >= 0)
+        assert np.all((e >= 0) == (we >= 0)), what
+        assert np.all(np.abs(t[hit] - wt[hit]) <= 1e-5 * np.abs(wt[hit])), what
+    return frac
+
+
+def test_rebuilt_tree_of_many_moving_instances_finds_the_reference_hits():
+    w, h = 320, 180
+    st1, st, whole = RenderSettings(w, h, 8, 1), RenderSettings(w, h, 4, 2), RenderChunk(0, 0, w, h)
+    moving = Scene(random_instances(1), 0)
+    worst = 0.0
+    for seed in (2, 3, 4, 2):                                # (every call builds from scratch; the last one revisits a layout)
+        b = random_instances(seed)
+        moving.rebuild_tlas(b)
+        fresh = Scene(b, 0)
+        hits = moving.primary_hits(st1, whole)
+        worst = max(worst, nearest_hit_gate(hits, fresh.primary_hits(st1, whole), ("fresh", seed)))
+        worst = max(worst, nearest_hit_gate(hits, OracleScene(b).primary_hits(st1, whole), ("oracle", seed)))
+        assert (hits[2] >= 0).mean() > 0.05
+        a, _, ca = moving.render_chunk(st, whole, seed=3)
+        f, _, cf = fresh.render_chunk(st, whole, seed=3)
+        bad = np.abs(a - f).max(axis=-1) > 2e-5
+        assert bad.mean() <= 2e-3, (seed, bad.mean())      # the bound of the image tests (decision flips of secondary rays)
+        fresh.close()
+    print(f"rebuilt TLAS, 300 instances: primary hits differ from the reference trees' on {worst * 100:.4f} % of the pixels at most")
+    moving.close()
+
+
+def test_interceptor_spin_rebuilt_on_8_angles():
+    """raytracer-samples/src/scene_interceptor_spin.rs:34-40 through the build instead of the refit."""
+    w, h = 320, 180
+    cfg = CameraConfiguration(w, h, lens_radius=0.1)
+    st1, whole = RenderSettings(w, h, 8, 1), RenderChunk(0, 0, w, h)
+    spun = Scene(SceneBuilder.sample("Interceptor Spin", cfg, params={"Time Ms": 0}), 0)
+    for k in range(1, 9):
+        b = SceneBuilder.sample("Interceptor Spin", cfg, params={"Time Ms": 1250.0 * k - 300.0})
+        spun.rebuild_tlas(b)
+        fresh = Scene(b, 0)
+        nearest_hit_gate(spun.primary_hits(st1, whole), fresh.primary_hits(st1, whole), k)
+        fresh.close()
+    spun.close()
+
+
+@pytest.mark.parametrize("name", ["Planes", "Mirrors", "Simple", "Mesh", "Random Spheres", "Fleet"])
+def test_rebuild_in_place_equals_the_built_scene(name):
+    """The entities where they were: infinite boxes (planes), one- and two-entity scenes (a root that is a leaf), 473 spheres,
+    1 331 instances - the rebuilt tree must find what the reference's tree finds."""
+    w, h = 256, 144
+    cfg = CameraConfiguration(w, h, lens_radius=0.0)
+    b = SceneBuilder.sample(name, cfg)
+    st1, st, whole = RenderSettings(w, h, 8, 1), RenderSettings(w, h, 5, 2), RenderChunk(0, 0, w, h)
+    built, scene = Scene(b, 0), Scene(b, 0)
+    scene.rebuild_tlas(b)
+    nearest_hit_gate(scene.primary_hits(st1, whole), built.primary_hits(st1, whole), name)
+    a, f = scene.render_chunk(st, whole, seed=5)[0], built.render_chunk(st, whole, seed=5)[0]
+    assert (np.abs(a - f).max(axis=-1) > 2e-5).mean() <= 2e-3, name
+    scene.close(); built.close()
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5])
+def test_rebuild_of_tiny_scenes(n):
+    w, h = 128, 72
+    st1, whole = RenderSettings(w, h, 8, 1), RenderChunk(0, 0, w, h)
+    scene = Scene(random_instances(1, n=n), 0)
+    b = random_instances(7, n=n)
+    scene.rebuild_tlas(b)
+    fresh = Scene(b, 0)
+    nearest_hit_gate(scene.primary_hits(st1, whole), fresh.primary_hits(st1, whole), n)
+    scene.close(); fresh.close()
+
+
+def test_a_rebuilt_tree_beats_a_refitted_one_when_entities_travel():
+    """Every instance jumps somewhere else: the refitted tree keeps the first frame's grouping (boxes that span the scene), the
+    rebuilt one does not.  Same pixels, different cost."""
+    w, h = 640, 360
+    st, whole = RenderSettings(w, h, 4, 8), RenderChunk(0, 0, w, h)
+    a, b = random_instances(1, n=2000), random_instances(2, n=2000)
+    refit, rebuilt, fresh = Scene(a, 0), Scene(a, 0), Scene(b, 0)
+    refit.update_transforms(b)
+    rebuilt.rebuild_tlas(b)
+
+    def seconds(scene):
+        scene.render_chunk(st, whole, seed=1, want_rgba=False)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            img = scene.render_chunk(st, whole, seed=1, want_rgba=False)[0]
+        return (time.perf_counter() - t0) / 3, img
+    (t_refit, i_refit), (t_rebuilt, i_rebuilt), (t_fresh, i_fresh) = seconds(refit), seconds(rebuilt), seconds(fresh)
+    assert np.array_equal(i_refit, i_fresh)                       # the refit is bit-exact (tests/test_gpu_refit.py) ...
+    assert (np.abs(i_rebuilt - i_fresh).max(axis=-1) > 2e-5).mean() <= 2e-3      # ... the rebuild nearest-hit exact
+    print(f"2000 instances after a jump: frame {t_refit * 1e3:.1f} ms on the refitted tree, {t_rebuilt * 1e3:.1f} ms on the rebuilt one, "
+          f"{t_fresh * 1e3:.1f} ms on the host-built one")
+    assert t_rebuilt < t_refit
+    for s in (refit, rebuilt, fresh):
+        s.close()
+
+
+def test_rebuild_latency_and_its_rules():
+    cfg = CameraConfiguration(640, 360, lens_radius=0.1)
+    a = SceneBuilder.sample("Doot Doot", cfg, params={"Count": 30, "Spacing": 30})
+    b = SceneBuilder.sample("Doot Doot", cfg, params={"Count": 30, "Spacing": 31})
+    t0 = time.perf_counter(); scene = Scene(a, 0); t_create = time.perf_counter() - t0
+    scene.rebuild_tlas(b)                                     # (first call: allocations, kernels load)
+    t0 = time.perf_counter()
+    for _ in range(10):
+        scene.rebuild_tlas(a); scene.rebuild_tlas(b)
+    t_rebuild = (time.perf_counter() - t0) / 20
+    st1, whole = RenderSettings(640, 360, 8, 1), RenderChunk(0, 0, 640, 360)
+    fresh = Scene(b, 0)
+    nearest_hit_gate(scene.primary_hits(st1, whole), fresh.primary_hits(st1, whole), "doot")
+    print(f"900 x 11 101 triangles: rt_scene_create {t_create * 1e3:.1f} ms, rt_scene_rebuild_tlas {t_rebuild * 1e3:.3f} ms")
+    assert t_rebuild < t_create / 3
+    with pytest.raises(RtError, match="rebuilt") as e:        # the refit tables describe the replaced tree
+        scene.update_transforms(a)
+    assert e.value.code == _ffi.RT_E_INVALID
+    with pytest.raises(RtError, match="sizes") as e:
+        scene.rebuild_tlas(SceneBuilder.sample("Doot Doot", cfg, params={"Count": 29, "Spacing": 30}))
+    assert e.value.code == _ffi.RT_E_INVALID
+    scene.close(); fresh.close()
