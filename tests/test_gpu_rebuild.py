@@ -82,6 +82,22 @@ def test_rebuild_in_place_equals_the_built_scene(name):
     scene.close(); built.close()
 
 
+def test_rebuild_of_a_200_000_sphere_cloud():
+    """A large top-level tree (raytracer-samples/src/scene_point_cloud.rs): keys collide, the tree gets deep, the records no longer fit any cache."""
+    w, h = 320, 180
+    b = SceneBuilder.sample("Point Cloud", CameraConfiguration(w, h, lens_radius=0.0), params={"Cloud Point Count": 200000})
+    st1, whole = RenderSettings(w, h, 8, 1), RenderChunk(0, 0, w, h)
+    built, scene = Scene(b, 0), Scene(b, 0)
+    t0 = time.perf_counter(); scene.rebuild_tlas(b); t_first = time.perf_counter() - t0
+    t0 = time.perf_counter(); scene.rebuild_tlas(b); t_again = time.perf_counter() - t0
+    hits = scene.primary_hits(st1, whole)
+    nearest_hit_gate(hits, built.primary_hits(st1, whole), "cloud")
+    assert (hits[2] >= 0).mean() > 0.2
+    print(f"200 000 spheres: rt_scene_rebuild_tlas {t_first * 1e3:.1f} ms (first call, allocates), {t_again * 1e3:.2f} ms after; depth {scene.info().tlas_depth} "
+          f"(host-built: {built.info().tlas_depth})")
+    scene.close(); built.close()
+
+
 @pytest.mark.parametrize("n", [1, 2, 3, 5])
 def test_rebuild_of_tiny_scenes(n):
     w, h = 128, 72
