@@ -10,6 +10,9 @@
  * build, same depth-first candidate order, same reducers.  Each function cites
  * the reference file:line it restates (paths relative to /root/reference).
  *
+ * One deliberate difference: the shadow ray's loop through transparent occluders (cast_light_ray_to_lamp) terminates
+ * where the reference's does not (see there).
+ *
  * "parity unpinned": the reference cannot be built here (no rustc); only
  * partition_by_key and create_render_chunks are pinned by the reference's own
  * tests.  XorShift/seed_from_u64 restate rand_xorshift 0.4.0 / rand_core 0.9.3
@@ -926,6 +929,10 @@ V3 cast_light_ray_to_lamp(V3 hit_point, const LightRecord& lr, TraceCtx& cx, Rng
             V3 albedo = texture_value(cx.s, (int32_t)shadow_hit.tex_id, shadow_hit);
             light_color = light_color * (albedo * shadow_mat.refr_intensity);
             closest_so_far = shadow_hit.t + BIAS;
+            // NOT the reference: beyond t = 65 536 the sum rounds back to t (ulp(t) > 2 BIAS), a plane or triangle accepts t == t_min
+            // (plane.rs:14, mesh.rs:28), and the reference's loop (:535-549) finds the same occluder for ever - it never returns
+            // the pixel.  The product cannot restate a hang: both it and this oracle step one ulp past the occluder instead.
+            if (!(closest_so_far > shadow_hit.t)) closest_so_far = std::nextafterf(shadow_hit.t, INFINITY);
             continue;
         }
         return ZERO;

@@ -802,6 +802,10 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                             const F3 albedo = texture_value<RICH>(S, hr.tex_id, hr);
                             lcol = lcol * (albedo * refr_intensity);                          // :541-543
                             closest = best.t + RT_BIAS;
+                            // NOT the reference: beyond t = 65 536 the sum rounds back to t, a plane or a triangle accepts t == t_min, and the
+                            // reference's loop finds the same occluder for ever (the pixel never returns; here: a kernel that never ends).
+                            // Step one ulp past the occluder instead (t > 0), as the oracle does.
+                            if (!(closest > best.t)) closest = __uint_as_float(__float_as_uint(best.t) + 1u);
                             state = SHADOW;                                                   // same ray, further on
                         }
                     }

@@ -97,3 +97,9 @@ def test_random_scene_matches_oracle(seed):
     check_image(rgb, ref, outlier_frac=5e-3, mean_atol=3e-4)
     assert cn.primary == rcn.rays.primary
     assert abs(cn.rays - (rcn.rays.primary + rcn.rays.secondary + rcn.rays.shadow)) <= max(8, 5e-3 * cn.rays)
+
+
+def test_shadow_ray_through_distant_glass_terminates():
+    """Seed 1245 (found by tools/fuzz_sweep.py): a shadow ray meets a refractive triangle 195 732 units away, where t + BIAS rounds back to
+    t; the reference's loop (implementation.rs:535-549) then finds the same occluder for ever.  Kernel and oracle step one ulp instead."""
+    test_random_scene_matches_oracle(245)

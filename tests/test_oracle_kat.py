@@ -277,3 +277,15 @@ def test_lights_known_answers():
     sun = RtLight(_ffi.RT_LIGHT_DIRECTIONAL, RtV3(), RtV3(0, -1, 0), RtV3(1, 1, 1), 0.5, 0.0)
     assert L.orc_light_record(C.byref(sun), p, out) == 1
     assert out[0] == np.float32(3.40282347e+38) and out[7] == 0.5
+
+
+@pytest.mark.timeout(60)
+def test_oracle_shadow_loop_terminates_beyond_t_65536():
+    """cast_light_ray_to_lamp advances by `t + BIAS`, which is `t` again beyond 65 536 (ulp > 2 BIAS); planes and triangles accept t == t_min,
+    so the reference's loop does not end on such a ray.  The oracle (and the kernel) step one ulp: random scene 1245 holds such rays."""
+    from tests.test_gpu_fuzz import random_scene, W, H
+    from tests.oracle import OracleScene, ORC_RNG_COUNTER_STRATIFIED
+    from raytracer_amd import RenderChunk, RenderSettings, sample_segment
+    o = OracleScene(random_scene(1245))
+    rgb, _, cn = o.render_chunk(RenderSettings(W, H, 5, 3), RenderChunk(0, 0, W, H), ORC_RNG_COUNTER_STRATIFIED, 245, sum_segment=sample_segment())
+    assert np.isfinite(rgb).all() and cn.rays.shadow > 0
