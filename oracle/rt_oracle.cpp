@@ -933,6 +933,7 @@ V3 cast_light_ray_to_lamp(V3 hit_point, const LightRecord& lr, TraceCtx& cx, Rng
             // (plane.rs:14, mesh.rs:28), and the reference's loop (:535-549) finds the same occluder for ever - it never returns
             // the pixel.  The product cannot restate a hang: both it and this oracle step one ulp past the occluder instead.
             if (!(closest_so_far > shadow_hit.t)) closest_so_far = std::nextafterf(shadow_hit.t, INFINITY);
+            if (!(closest_so_far > shadow_hit.t)) return ZERO;      // (t = inf: nothing lies further on)
             continue;
         }
         return ZERO;

@@ -806,7 +806,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                             // reference's loop finds the same occluder for ever (the pixel never returns; here: a kernel that never ends).
                             // Step one ulp past the occluder instead (t > 0), as the oracle does.
                             if (!(closest > best.t)) closest = __uint_as_float(__float_as_uint(best.t) + 1u);
-                            state = SHADOW;                                                   // same ray, further on
+                            if (closest > best.t) state = SHADOW;                             // same ray, further on (an occluder at t = inf: no light, as if opaque)
                         }
                     }
                     if (state == NEED_LIGHT) light_k++;                                      // opaque: ZERO (:548)
