@@ -1,0 +1,117 @@
+"""One-off randomized sweep of the size-independent properties the parity suite checks on fixed sizes: for random scenes
+(tests/test_gpu_fuzz.py's generator) at random image sizes, sample counts, depths, lens settings and options, the frame must be
+bit-identical however it is produced -
+  whole frame == random chunk grid == strips of a random rank count == sample ranges accumulated and resolved
+  == rt_render_chunk_device_noalloc == the host-pointer call (rgb and rgba = `as u8` of the floats) == the same call again,
+and close to the oracle in the scene's lens mode.
+   usage: python tools/invariant_sweep.py <first seed> <count>"""
+import os, sys, time, traceback
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from raytracer_amd import RenderChunk, RenderSettings, Scene, create_render_chunks, resolve_device, sample_segment, strip_rows
+from raytracer_amd.dist import sample_range_of_rank
+from tests.oracle import OracleScene, use_lens_mode
+from tests.test_gpu_fuzz import random_scene
+from tests.test_gpu_parity import check_image
+
+DEV = "cuda:0"
+
+
+def one(seed):
+    r = np.random.default_rng(seed)
+    b = random_scene(5000 + seed)
+    w, h = int(r.integers(9, 150)), int(r.integers(9, 100))
+    spp, depth = int(r.choice([1, 2, 3, 7, 8, 9, 16, 17, 24, 33, 64])), int(r.integers(0, 9))
+    # (the generator's camera carries its own lens radius)
+    st = RenderSettings(w, h, depth, spp)
+    scene = Scene(b, 0)
+    lens_mode = "reference" if r.integers(0, 2) else "stratified"
+    rng_mode = use_lens_mode(scene, lens_mode)
+    if r.integers(0, 3) == 0:
+        scene.set_option("fine_split", int(r.choice([-1, 1])))
+    if r.integers(0, 3) == 0:
+        scene.set_option("round_units", int(r.choice([1, 2, 4, 8])))
+    if r.integers(0, 3) == 0:
+        scene.set_option("lens_coc_px", float(r.choice([0.0, 1.0, 1e9])))
+    sm = torch.cuda.current_stream().cuda_stream
+    whole = RenderChunk(0, 0, w, h)
+    render_seed = int(r.integers(0, 2**31))
+
+    def buf():
+        return torch.zeros((h, w, 3), dtype=torch.float32, device=DEV)
+    frame = buf()
+    scene.render_chunk_device(st, whole, render_seed, frame.data_ptr(), None, w, 0, 0, None, sm)
+    torch.cuda.synchronize()
+    what = f"seed {seed}: {w}x{h} spp {spp} depth {depth} lens {lens_mode}"
+    # again
+    again = buf()
+    scene.render_chunk_device(st, whole, render_seed, again.data_ptr(), None, w, 0, 0, None, sm)
+    torch.cuda.synchronize()
+    assert torch.equal(again, frame), what + ": re-render"
+    # chunk grid
+    tiled = buf()
+    for c in create_render_chunks((w, h), (int(r.integers(1, 6)), int(r.integers(1, 6)))):
+        if c.width and c.height:
+            scene.render_chunk_device(st, c, render_seed, tiled.data_ptr(), None, w, c.left, c.top, None, sm)
+    torch.cuda.synchronize()
+    assert torch.equal(tiled, frame), what + ": chunk grid"
+    # strips
+    world, sh = int(r.integers(2, 7)), 8
+    out = buf()
+    for k in range(world):
+        rows = strip_rows(h, sh, k, world)
+        if rows == 0:
+            continue
+        packed = torch.zeros((rows, w, 3), dtype=torch.float32, device=DEV)
+        scene.render_strips_device(st, sh, k, world, render_seed, packed.data_ptr(), None, None, sm)
+        idx = torch.tensor([y for top in range(k * sh, h, world * sh) for y in range(top, min(top + sh, h))], device=DEV)
+        out.index_copy_(0, idx, packed)
+    torch.cuda.synchronize()
+    assert torch.equal(out, frame), what + f": {world}-rank strips"
+    # sample ranges
+    parts = int(r.integers(2, 6))
+    acc = buf()
+    for k in range(parts):
+        first, count = sample_range_of_rank(spp, k, parts)
+        if count:
+            scene.accumulate_chunk_device(st, whole, render_seed, first, count, acc.data_ptr(), None, sm)
+    res = buf()
+    resolve_device(0, acc.data_ptr(), w * h, spp, res.data_ptr(), None, sm)
+    torch.cuda.synchronize()
+    assert torch.equal(res, frame), what + f": {parts} sample ranges"
+    # the allocation-free entry point
+    na = buf()
+    scene.render_chunk_device_noalloc(st, whole, render_seed, na.data_ptr(), None, w, 0, 0, None, sm)
+    torch.cuda.synchronize()
+    assert torch.equal(na, frame), what + ": noalloc"
+    # host-pointer call, bytes
+    rgb, rgba, cn = scene.render_chunk(st, whole, seed=render_seed)
+    host = frame.cpu().numpy()
+    assert np.array_equal(rgb, host), what + ": host call"
+    want = np.clip(np.nan_to_num(255.0 * host.astype(np.float32), nan=0.0), 0, 255).astype(np.uint8)
+    assert np.array_equal(rgba[..., :3], want) and np.all(rgba[..., 3] == 255), what + ": rgba"
+    # the oracle
+    ref, _, rcn = OracleScene(b).render_chunk(st, whole, rng_mode, render_seed, sum_segment=sample_segment())
+    assert cn.primary == rcn.rays.primary, what + ": primary rays"
+    # (decision flips of deep secondary rays change whole pixels, and the images are small: at most 3 pixels or 1 %)
+    n_out = int((np.abs(rgb.astype(np.float64) - ref).max(axis=-1) > 2e-5).sum())
+    assert n_out <= max(3, 0.01 * w * h), what + f": {n_out} of {w * h} pixels differ from the oracle"
+    scene.close()
+
+
+first, count = int(sys.argv[1]), int(sys.argv[2])
+bad, t0 = [], time.perf_counter()
+for k, seed in enumerate(range(first, first + count)):
+    try:
+        one(seed)
+    except AssertionError as e:
+        bad.append(seed)
+        print("FAILED", str(e)[:300].replace("\n", " "), flush=True)
+    except Exception:
+        bad.append(seed)
+        print("ERROR seed", seed, traceback.format_exc().splitlines()[-4:], flush=True)
+    if (k + 1) % 20 == 0:
+        print(f"{k + 1} cases, {len(bad)} failures, {time.perf_counter() - t0:.1f} s", flush=True)
+print("done:", count, "cases, failures:", bad, flush=True)
+sys.exit(1 if bad else 0)
