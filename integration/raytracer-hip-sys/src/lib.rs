@@ -356,6 +356,18 @@ impl GpuScene {
         check(unsafe { rt_scene_set_option(self.handle, option, value) })
     }
 
+    /// Animated scenes (`scene_interceptor_spin.rs:34-40` rebuilds everything per frame): new transforms for the same entities.
+    /// `rebuild == false`: the TLAS is refitted on the device (hits bit-identical to a fresh scene); `rebuild == true`: a new
+    /// TLAS is built on the device (for entities that travel; nearest hits are the reference's, the tree is not).
+    /// `&mut self`: no render call may be in flight.
+    pub fn move_entities(&mut self, translations: &[RtV3], rotations: &[RtRotation], rebuild: bool) -> Result<(), GpuError> {
+        let (t, nt, r, nr) = (translations.as_ptr(), translations.len() as u64, rotations.as_ptr(), rotations.len() as u64);
+        check(unsafe {
+            if rebuild { rt_scene_rebuild_tlas(self.handle, t, nt, r, nr, std::ptr::null_mut()) }
+            else { rt_scene_update_transforms(self.handle, t, nt, r, nr, std::ptr::null_mut()) }
+        })
+    }
+
     pub fn as_ptr(&self) -> *mut RtScene {
         self.handle
     }
