@@ -238,8 +238,10 @@ __device__ __forceinline__ void ray_to_entity(const DevSceneView& S, const Word4
 // = EntityBvhRoot::try_hit (:411-416) over Entity::hit (:285-310) over
 // Sphere::hit / Plane::hit / MeshBvhRoot::try_hit (sphere.rs:36-53, plane.rs:59-90,
 // mesh.rs:92-99).  `stack` is this lane's LDS column (stride RT_BLOCK dwords).
+// (WIDE / `wide`: the 4-wide walk of the diagnostics build -DRT_BVH4_EXPERIMENT, rt_debug_bvh4_primary below; never in the product)
+template <bool WIDE = false>
 __device__ __forceinline__ void trace(const DevSceneView& S, const F3 wo, const F3 wd, const float t_min, const float t_max,
-                                      uint32_t* stack, const uint32_t stack_cap, uint32_t* error_flag, Hit& best) {
+                                      uint32_t* stack, const uint32_t stack_cap, uint32_t* error_flag, Hit& best, const Word4* wide = nullptr) {
     best.t = t_max; best.ent = RT_NONE; best.tri = RT_NONE; best.erank = 0;
     float best_t = t_max;                 // culling bound; primitives test against [t_min, t_max]
 
@@ -266,6 +268,37 @@ __device__ __forceinline__ void trace(const DevSceneView& S, const F3 wo, const 
         // ---- phase 1: walk inner nodes until this lane holds a leaf (RT_NONE has the
         // leaf bit set and ends the walk too).  One 64-byte record = two boxes. ------
         while (cur < RT_REF_LEAF_BIT) {
+#ifdef RT_BVH4_EXPERIMENT
+            if (WIDE) {
+                // one 128-byte record = up to four child boxes (lo.x[4] lo.y[4] lo.z[4] hi.x[4] hi.y[4] hi.z[4] refs[4]); the children that are hit
+                // are visited nearest first: a 5-comparator network on (entry distance, ref), the rest pushed farthest first
+                const Word4* n = wide + (size_t)cur * 8;
+                const Word4 lx = ldw(n), ly = ldw(n + 1), lz = ldw(n + 2), hx = ldw(n + 3), hy = ldw(n + 4), hz = ldw(n + 5), rf = ldw(n + 6);
+                const float bound = (S.loose_boxes && inst_sp == RT_NONE) ? t_max : best_t;
+                float k[4]; uint32_t r4[4]; uint32_t hits = 0;
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    float e;
+                    const bool h = slab(lx.f[c], ly.f[c], lz.f[c], hx.f[c], hy.f[c], hz.f[c], o, inv, t_min, bound, e);
+                    k[c] = h ? e : __builtin_inff(); r4[c] = rf.u[c]; hits += h ? 1u : 0u;
+                }
+                auto cswap = [&](int a, int b) {
+                    const bool sw = k[b] < k[a];
+                    const float ka = sw ? k[b] : k[a], kb = sw ? k[a] : k[b];
+                    const uint32_t ra = sw ? r4[b] : r4[a], rb = sw ? r4[a] : r4[b];
+                    k[a] = ka; k[b] = kb; r4[a] = ra; r4[b] = rb;
+                };
+                cswap(0, 1); cswap(2, 3); cswap(0, 2); cswap(1, 3); cswap(1, 2);
+                if (hits == 0u) { cur = pop(); continue; }
+                for (int c = 3; c >= 1; c--)
+                    if (hits > (uint32_t)c) {
+                        if (sp < stack_cap) stack[(sp++) * RT_BLOCK] = r4[c];
+                        else *error_flag = RT_DEVERR_STACK;
+                    }
+                cur = r4[0];
+                continue;
+            }
+#endif
             const Word4* n = nodes[cur].w;
             const Word4 a = ldw(n), b = ldw(n + 1), c = ldw(n + 2), r = ldw(n + 3);
             float el, er; bool hl, hr;
@@ -1403,6 +1436,27 @@ primary_kernel(const DevSceneView S, const RenderParams P, float* t_out, float* 
     if (tri_out) tri_out[i] = tri;
 }
 
+#ifdef RT_BVH4_EXPERIMENT
+// diagnostics build only: primary hits through the 4-wide walk (rt_debug_bvh4_primary)
+__global__ void __launch_bounds__(RT_BLOCK)
+primary_wide_kernel(const DevSceneView S, const RenderParams P, const Word4* wide, uint32_t stack_cap, float* t_out, int32_t* e_out, int32_t* tri_out) {
+    extern __shared__ uint32_t lds_stack[];
+    uint32_t* stack = lds_stack + threadIdx.x;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.cw * P.ch) return;
+    const uint32_t x = i % P.cw, y = i / P.cw;
+    F3 o, d;
+    float pu, pv;
+    pixel_uv(P, P.left + x, P.top + y, pu, pv);
+    gen_camera_ray(S, pu, pv, 0.0f, 0.0f, o, d);
+    Hit h;
+    if (wide) trace<true>(S, o, d, RT_BIAS, RT_F32_MAX, stack, stack_cap, P.error_flag, h, wide);
+    else trace<false>(S, o, d, RT_BIAS, RT_F32_MAX, stack, stack_cap, P.error_flag, h);
+    t_out[i] = h.ent != RT_NONE ? h.t : -1.0f;
+    e_out[i] = (int32_t)h.ent; tri_out[i] = (int32_t)h.tri;
+}
+#endif
+
 // ===========================================================================
 // refit of the TLAS after a change of the entity transforms (rt_scene_update_transforms)
 // ===========================================================================
@@ -2299,6 +2353,76 @@ int rt_primary_hits(RtScene* scene, const RtSettings* st, const RtRenderChunk* c
     HIP_TRY(hipStreamSynchronize(ws.stream));
     return check_device_error(scene);
 }
+
+#ifdef RT_BVH4_EXPERIMENT
+// Diagnostics build only (make bvh4, tools/bvh4_probe.py): the measurement behind DESIGN.md 4.2's "a 4-wide node was not built".
+// Collapses the scene's two-box records into 4-wide ones (children of an inner child take its place; leaves stay), walks both
+// trees with the primary rays of a chunk `reps` times and reports kernel times and the number of pixels whose hit differs (0).
+int rt_debug_bvh4_primary(RtScene* scene, const RtSettings* st, const RtRenderChunk* ch, int reps, double* ms_binary, double* ms_wide, uint64_t* mismatches) {
+    int rc = validate_call(scene, st, ch);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(scene->device));
+    const size_t nn = scene->node_count, npix = (size_t)ch->width * ch->height;
+    std::vector<DevNode> bin(nn);
+    HIP_TRY(hipMemcpy(bin.data(), scene->view.nodes, nn * sizeof(DevNode), hipMemcpyDeviceToHost));
+    std::vector<Word4> wide(nn * 8);
+    const float inf = __builtin_inff();
+    for (size_t i = 0; i < nn; i++) {
+        Word4* w = &wide[i * 8];
+        for (int c = 0; c < 4; c++) { w[0].f[c] = w[1].f[c] = w[2].f[c] = inf; w[3].f[c] = w[4].f[c] = w[5].f[c] = -inf; w[6].u[c] = RT_NONE; w[7].u[c] = 0; }
+        int slot = 0;
+        auto put = [&](const DevNode& src, int side, uint32_t ref) {      // child `side` (0 left, 1 right) of record src
+            const float* f = src.w[0].f;
+            w[0].f[slot] = f[0 + side]; w[1].f[slot] = f[2 + side]; w[2].f[slot] = f[4 + side];
+            w[3].f[slot] = f[6 + side]; w[4].f[slot] = f[8 + side]; w[5].f[slot] = f[10 + side];
+            w[6].u[slot] = ref; slot++;
+        };
+        for (int side = 0; side < 2; side++) {
+            const uint32_t ref = bin[i].w[3].u[side];
+            if (ref < RT_REF_LEAF_BIT && ref < nn) { put(bin[ref], 0, bin[ref].w[3].u[0]); put(bin[ref], 1, bin[ref].w[3].u[1]); }
+            else put(bin[i], side, ref);
+        }
+    }
+    Word4* wide_dev = nullptr; float* t_dev[2]; int32_t *e_dev[2], *tri_dev[2];
+    HIP_TRY(hipMalloc((void**)&wide_dev, wide.size() * sizeof(Word4)));
+    HIP_TRY(hipMemcpy(wide_dev, wide.data(), wide.size() * sizeof(Word4), hipMemcpyHostToDevice));
+    for (int v = 0; v < 2; v++) { HIP_TRY(hipMalloc((void**)&t_dev[v], npix * 4)); HIP_TRY(hipMalloc((void**)&e_dev[v], npix * 4)); HIP_TRY(hipMalloc((void**)&tri_dev[v], npix * 4)); }
+    RenderParams P{};
+    P.width = st->width; P.height = st->height; P.max_reflections = st->max_reflections; P.spp = 1;
+    P.left = ch->left; P.top = ch->top; P.cw = ch->width; P.ch = ch->height;
+    P.error_flag = scene->dev_error_dev;
+    // stack: the two-box walk gets what the scene build sized; a wide step pushes up to three refs, so the wide walk gets RT_BVH4_STACK_PCT
+    // per cent of that (default 150; an overflow sets the scene's sticky error).  LDS per block, hence occupancy, follows.
+    const char* pct_env = getenv("RT_BVH4_STACK_PCT");
+    const uint32_t pct = pct_env ? (uint32_t)atoi(pct_env) : 150u;
+    const uint32_t caps[2] = {scene->view.stack_entries, (scene->view.stack_entries * pct + 99u) / 100u};
+    hipEvent_t e0, e1; HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    double ms[2] = {0, 0};
+    for (int v = 0; v < 2; v++) {
+        for (int r = -1; r < reps; r++) {                             // (one untimed launch first)
+            if (r == 0) HIP_TRY(hipEventRecord(e0, 0));
+            hipLaunchKernelGGL(primary_wide_kernel, dim3((uint32_t)((npix + RT_BLOCK - 1) / RT_BLOCK)), dim3(RT_BLOCK), (size_t)caps[v] * RT_BLOCK * sizeof(uint32_t), 0, scene->view, P,
+                               v ? (const Word4*)wide_dev : (const Word4*)nullptr, caps[v], t_dev[v], e_dev[v], tri_dev[v]);
+        }
+        HIP_TRY(hipEventRecord(e1, 0)); HIP_TRY(hipEventSynchronize(e1));
+        float f = 0; HIP_TRY(hipEventElapsedTime(&f, e0, e1)); ms[v] = f / (reps > 0 ? reps : 1);
+    }
+    std::vector<float> t[2]; std::vector<int32_t> e[2], tri[2];
+    for (int v = 0; v < 2; v++) {
+        t[v].resize(npix); e[v].resize(npix); tri[v].resize(npix);
+        HIP_TRY(hipMemcpy(t[v].data(), t_dev[v], npix * 4, hipMemcpyDeviceToHost)); HIP_TRY(hipMemcpy(e[v].data(), e_dev[v], npix * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(tri[v].data(), tri_dev[v], npix * 4, hipMemcpyDeviceToHost));
+        (void)hipFree(t_dev[v]); (void)hipFree(e_dev[v]); (void)hipFree(tri_dev[v]);
+    }
+    (void)hipFree(wide_dev); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    uint64_t bad = 0;
+    for (size_t i = 0; i < npix; i++) bad += (memcmp(&t[0][i], &t[1][i], 4) != 0 || e[0][i] != e[1][i] || tri[0][i] != tri[1][i]) ? 1 : 0;
+    if (ms_binary) *ms_binary = ms[0];
+    if (ms_wide) *ms_wide = ms[1];
+    if (mismatches) *mismatches = bad;
+    return check_device_error(scene);
+}
+#endif
 
 int rt_create_render_chunks(uint32_t width, uint32_t height, uint32_t count_x, uint32_t count_y, RtRenderChunk* out, uint32_t capacity) {
     int rc = host_create_render_chunks(width, height, count_x, count_y, out, capacity);
