@@ -256,7 +256,8 @@ int rt_scene_update_transforms(RtScene* scene, const RtV3* translations, uint64_
  * exact ties keep the reference's visit ranks.  After this call rt_scene_update_transforms is refused (its tables describe
  * the replaced tree) and rt_scene_bvh_order(-1) still reports the tree of rt_scene_create.  The first call allocates
  * (about 150 bytes per entity + 64 per entity of node records).  Enqueued on `stream`, then waits for it.  No render call
- * on this scene may be in flight.  RT_E_DEPTH: the new tree is deeper than the LDS traversal stack can hold (64 levels);
+ * on this scene may be in flight.  RT_E_INVALID (nothing changed): some rotation axis is not of unit length - such an entity's box
+ * does not bound its hits, and only the reference's own tree reproduces what the reference then reports.  RT_E_DEPTH: the new tree is deeper than the LDS traversal stack can hold (64 levels);
  * the scene must then be created anew. */
 int rt_scene_rebuild_tlas(RtScene* scene, const RtV3* translations, uint64_t translation_count,
                           const RtRotation* rotations, uint64_t rotation_count, void* stream);

@@ -2194,6 +2194,11 @@ int rt_scene_rebuild_tlas(RtScene* scene, const RtV3* translations, uint64_t tra
     bool loose = false;
     host_make_xforms(scene->desc_entities.data(), scene->tlas_perm, translations, rotations, scene->xforms_host, loose);
     if (scene->xforms_host.size() != scene->xforms_words) return set_error(RT_E_INVALID, "rt_scene_rebuild_tlas: internal size mismatch");
+    // A rotation about an axis that is not of unit length scales the entity (types.rs:200), so its box (calculate_origin_aabb) does not bound its
+    // hits and WHICH hits the reference reports depends on the boxes of its own tree (DevSceneView::loose_boxes): no other tree reproduces them
+    // (measured: 62 of 323 such random scenes differ).  Nothing on the device has been touched yet.
+    if (loose) return set_error(RT_E_INVALID, "rt_scene_rebuild_tlas: a rotation axis is not of unit length - entity boxes do not bound their hits, only the reference's own tree "
+                                              "reproduces them; use rt_scene_update_transforms (refit) or rt_scene_create");
     Word4* xforms_dev = const_cast<Word4*>(scene->view.xforms);
     DevNode* nodes_dev = const_cast<DevNode*>(scene->view.nodes);
     DevEntity* ent_cur = const_cast<DevEntity*>(scene->view.entities);

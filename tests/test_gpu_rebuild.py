@@ -158,3 +158,22 @@ def test_rebuild_latency_and_its_rules():
         scene.rebuild_tlas(SceneBuilder.sample("Doot Doot", cfg, params={"Count": 29, "Spacing": 30}))
     assert e.value.code == _ffi.RT_E_INVALID
     scene.close(); fresh.close()
+
+
+def test_rebuild_refuses_entities_whose_boxes_do_not_bound():
+    """A rotation about a non-unit axis scales the entity (types.rs:200): its box no longer bounds its hits and which hits the reference
+    reports depends on ITS tree (62 of 323 such random scenes differ under another tree).  The refit keeps that tree; the build refuses."""
+    b = SceneBuilder(camera_new((0.0, 2.0, 10.0), (0, 0, 0), 45.0, 16 / 9, 0.0, 10.0), _ffi.RT_SKY_DAY)
+    m, t = b.add_lambertian(0.0), b.add_color_texture((0.5, 0.5, 0.5))
+    for k in range(6):
+        b.add_sphere_entity(0.5, m, t, translations=[(k - 2.5, 0.0, 0.0)], rotations=[((0.0, 2.0, 0.0), 0.3)], id=k)
+    scene = Scene(b, 0)
+    st1, whole = RenderSettings(128, 72, 8, 1), RenderChunk(0, 0, 128, 72)
+    before = scene.primary_hits(st1, whole)
+    with pytest.raises(RtError, match="unit length") as e:
+        scene.rebuild_tlas(b)
+    assert e.value.code == _ffi.RT_E_INVALID
+    scene.update_transforms(b)                                  # nothing was changed: the refit still works, the hits are the same
+    after = scene.primary_hits(st1, whole)
+    assert all(np.array_equal(x, y) for x, y in zip(before, after))
+    scene.close()
