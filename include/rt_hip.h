@@ -244,7 +244,9 @@ void     rt_scene_destroy(RtScene* scene);
  * them are recomputed ON THE DEVICE (refit: the tree keeps the topology, leaves and visit ranks it was built with, BLASes
  * are untouched); the host only evaluates sin / cos of the rotation angles, with the libm the reference calls per ray.
  * Hits are those of a fresh rt_scene_create of the moved scene, except which of two entities wins an EXACT tie in t (the
- * visit ranks are those of the original tree).  Enqueued on `stream`, then waits for it (the host needs the new root box).
+ * visit ranks are those of the original tree).  RT_E_INVALID (nothing changed): some rotation axis is not of unit length - such an
+ * entity's box does not bound its hits, and what the reference then reports depends on the leaves of the tree it builds for the
+ * new transforms: create the scene anew.  Enqueued on `stream`, then waits for it (the host needs the new root box).
  * No render call on this scene may be in flight. */
 int rt_scene_update_transforms(RtScene* scene, const RtV3* translations, uint64_t translation_count,
                                const RtRotation* rotations, uint64_t rotation_count, void* stream);
