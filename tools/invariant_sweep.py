@@ -57,7 +57,7 @@ def one(seed):
     torch.cuda.synchronize()
     assert torch.equal(tiled, frame), what + ": chunk grid"
     # strips
-    world, sh = int(r.integers(2, 7)), 8
+    world, sh = int(r.integers(2, 7)), int(r.choice([8, 8, 16, 24]))
     out = buf()
     for k in range(world):
         rows = strip_rows(h, sh, k, world)
@@ -80,6 +80,15 @@ def one(seed):
     resolve_device(0, acc.data_ptr(), w * h, spp, res.data_ptr(), None, sm)
     torch.cuda.synchronize()
     assert torch.equal(res, frame), what + f": {parts} sample ranges"
+    # ranges that cut through sample segments: the same samples, summed in another association (close, not identical)
+    if spp >= 3:
+        cut = sorted(set(int(v) for v in r.integers(1, spp, size=2)))
+        acc.zero_()
+        for lo, hi in zip([0] + cut, cut + [spp]):
+            scene.accumulate_chunk_device(st, whole, render_seed, lo, hi - lo, acc.data_ptr(), None, sm)
+        resolve_device(0, acc.data_ptr(), w * h, spp, res.data_ptr(), None, sm)
+        torch.cuda.synchronize()
+        assert float((res - frame).abs().max()) <= 1e-5, what + f": ragged sample ranges {cut}"
     # the allocation-free entry point
     na = buf()
     scene.render_chunk_device_noalloc(st, whole, render_seed, na.data_ptr(), None, w, 0, 0, None, sm)
