@@ -285,3 +285,27 @@ def test_scene_options_are_validated():
         assert e.value.code == _ffi.RT_E_INVALID
     with pytest.raises(RtError, match="unknown option"):
         scene._check(scene._lib.rt_scene_set_option(scene._h, 77, 0.0))
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("what", ["nan position", "inf position", "nan radius", "negative radius", "huge radius", "nan angle", "1e20 position"])
+def test_non_finite_scene_data_neither_hangs_nor_poisons_the_frame(what):
+    """The reference does not validate scene data and neither does rt_scene_create; whatever the values, the build returns, every loop of the
+    kernel ends and the pixels are finite (cast_ray clamps each sample, types.rs:46-50; a NaN compares false everywhere)."""
+    from raytracer_amd import camera_new
+    mut = {"nan position": {"pos": (float("nan"), 0.0, 0.0)}, "inf position": {"pos": (float("inf"), 0.0, 0.0)}, "nan radius": {"radius": float("nan")},
+           "negative radius": {"radius": -1.0}, "huge radius": {"radius": 1e30}, "nan angle": {"theta": float("nan")}, "1e20 position": {"pos": (1e20, 0.0, 0.0)}}[what]
+    b = SceneBuilder(camera_new((0.0, 2.0, 10.0), (0, 0, 0), 45.0, 16 / 9, 0.05, 10.0), _ffi.RT_SKY_DAY)
+    m, g, t = b.add_lambertian(0.3), b.add_dielectric(1.0, 0.0, 1.5), b.add_color_texture((0.5, 0.5, 0.5))
+    mesh = b.add_mesh(np.array([[[-1, 0, 0], [1, 0, 0], [0, 1.5, 0]]], dtype=np.float32))
+    for k in range(40):
+        pos = mut.get("pos") if k == 7 and "pos" in mut else (k * 0.5 - 10.0, 0.0, 0.0)
+        if k % 2:
+            b.add_sphere_entity(mut.get("radius", 0.5) if k == 9 else 0.5, g if k % 3 == 0 else m, t, translations=[pos], id=k)
+        else:
+            b.add_mesh_entity(mesh, m, t, translations=[pos], rotations=[((0.0, 1.0, 0.0), mut.get("theta", 0.3) if k == 8 else 0.3)], id=k)
+    b.add_point_light((0, 10, 0), 100.0)
+    scene = Scene(b, 0)
+    rgb, rgba, cn = scene.render_chunk(RenderSettings(160, 90, 8, 8), RenderChunk(0, 0, 160, 90), seed=1)
+    assert np.isfinite(rgb).all() and np.abs(rgb).max() <= 1.0 and cn.primary == 160 * 90 * 8
+    scene.close()
