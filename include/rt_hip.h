@@ -255,8 +255,8 @@ int rt_scene_update_transforms(RtScene* scene, const RtV3* translations, uint64_
  * bvh.rs:129-188, is a CPU mean-split build per frame).  For animations in which entities travel: a refitted tree keeps
  * the grouping of the first frame and degrades.  The tree differs from the reference's, so candidates are pruned by other
  * boxes: the nearest hit is the reference's except where a ray grazes the boundary of an entity's own box (f32 rounding),
- * exact ties keep the reference's visit ranks.  After this call rt_scene_update_transforms is refused (its tables describe
- * the replaced tree) and rt_scene_bvh_order(-1) still reports the tree of rt_scene_create.  The first call allocates
+ * exact ties keep the reference's visit ranks.  After this call rt_scene_update_transforms refits THIS tree (same gate as
+ * the build) and rt_scene_bvh_order(-1) still reports the tree of rt_scene_create.  The first call allocates
  * (about 150 bytes per entity + 64 per entity of node records).  Enqueued on `stream`, then waits for it.  No render call
  * on this scene may be in flight.  RT_E_INVALID (nothing changed): some rotation axis is not of unit length - such an entity's box
  * does not bound its hits, and only the reference's own tree reproduces what the reference then reports.  RT_E_DEPTH: the new tree is deeper than the LDS traversal stack can hold (64 levels);

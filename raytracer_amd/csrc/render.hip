@@ -2116,7 +2116,6 @@ int rt_scene_update_transforms(RtScene* scene, const RtV3* translations, uint64_
     if (scene->device == RT_DEVICE_HOST_ONLY) return set_error(RT_E_NO_DEVICE, "scene was created host-only");
     if (translation_count != scene->n_translations || rotation_count != scene->n_rotations)
         return set_error(RT_E_INVALID, "rt_scene_update_transforms: the arrays must have the sizes given to rt_scene_create (entities keep their ranges)");
-    if (!scene->refit_valid) return set_error(RT_E_INVALID, "rt_scene_update_transforms: the tree was rebuilt on the device (rt_scene_rebuild_tlas); its refit tables are gone - rebuild again");
     if ((translation_count && !translations) || (rotation_count && !rotations)) return set_error(RT_E_INVALID, "null transform array");
     std::lock_guard<std::mutex> g(scene->lock);
     HIP_TRY(hipSetDevice(scene->device));
@@ -2138,10 +2137,23 @@ int rt_scene_update_transforms(RtScene* scene, const RtV3* translations, uint64_
     const uint32_t n = scene->view.entity_count;
     hipLaunchKernelGGL(refit_entities_kernel, dim3((n + 255) / 256), dim3(256), 0, sm, entities_dev, (const Word4*)xforms_dev, scene->view.meshes, scene->ent_box_dev, n);
     HIP_TRY_SYNC(hipGetLastError(), sm);
-    for (size_t l = 0; l + 1 < scene->refit_level_start.size(); l++) {
-        const uint32_t first = scene->refit_level_start[l], count = scene->refit_level_start[l + 1] - first;
-        if (count == 0) continue;
-        hipLaunchKernelGGL(refit_level_kernel, dim3((count + 255) / 256), dim3(256), 0, sm, nodes_dev, scene->refit_dev, first, count, (const float*)scene->ent_box_dev);
+    if (scene->refit_valid) {
+        for (size_t l = 0; l + 1 < scene->refit_level_start.size(); l++) {
+            const uint32_t first = scene->refit_level_start[l], count = scene->refit_level_start[l + 1] - first;
+            if (count == 0) continue;
+            hipLaunchKernelGGL(refit_level_kernel, dim3((count + 255) / 256), dim3(256), 0, sm, nodes_dev, scene->refit_dev, first, count, (const float*)scene->ent_box_dev);
+            HIP_TRY_SYNC(hipGetLastError(), sm);
+        }
+    } else if (n > RT_LBVH_LEAF) {
+        // the tree was built on the device (rt_scene_rebuild_tlas): its topology and record numbers are still in the build's buffers, so a refit
+        // is the build without the sort: boxes bottom-up, records rewritten
+        RtScene::TlasRebuild& rb = scene->rebuild;
+        const dim3 blk(256), per_entity((n + 255) / 256), per_inner((n - 1 + 255) / 256);
+        HIP_TRY_SYNC(hipMemsetAsync(rb.arrived, 0, (size_t)(n - 1) * 4, sm), sm);
+        hipLaunchKernelGGL(lbvh_boxes_kernel, per_entity, blk, 0, sm, (const LbvhNode*)rb.lnodes, (const uint32_t*)rb.parent, n, (const float*)scene->ent_box_dev, rb.box,
+                           rb.height, rb.arrived);
+        hipLaunchKernelGGL(lbvh_emit_kernel, per_inner, blk, 0, sm, (const LbvhNode*)rb.lnodes, n, (const uint32_t*)rb.number, (const float*)rb.box,
+                           (const float*)scene->ent_box_dev, nodes_dev);
         HIP_TRY_SYNC(hipGetLastError(), sm);
     }
     float* root_dev = scene->ent_box_dev + (size_t)n * 8;

@@ -18,7 +18,7 @@ for k, seed in enumerate(range(first, first + count)):
         a, b = random_instances(10 * seed + 1, n=n), random_instances(10 * seed + 2, n=n)
         refit, rebuilt, fresh = Scene(a, 0), Scene(a, 0), Scene(b, 0)
         refit.update_transforms(b); rebuilt.rebuild_tlas(b)
-        want = fresh.primary_hits(st1, whole)
+        want = want_b = fresh.primary_hits(st1, whole)
         assert same_hits(refit.primary_hits(st1, whole), want), f"seed {seed} n {n}: refit hits"
         worst = max(worst, nearest_hit_gate(rebuilt.primary_hits(st1, whole), want, f"seed {seed} n {n}: rebuilt hits"))
         f = fresh.render_chunk(st, whole, seed=3)[0]
@@ -29,6 +29,8 @@ for k, seed in enumerate(range(first, first + count)):
         want = back.primary_hits(st1, whole)
         assert same_hits(refit.primary_hits(st1, whole), want), f"seed {seed} n {n}: refit back"
         worst = max(worst, nearest_hit_gate(rebuilt.primary_hits(st1, whole), want, f"seed {seed} n {n}: rebuilt back"))
+        rebuilt.update_transforms(b)                                  # a refit of the device-built tree
+        worst = max(worst, nearest_hit_gate(rebuilt.primary_hits(st1, whole), want_b, f"seed {seed} n {n}: refit of the built tree"))
         for s in (refit, rebuilt, fresh, back):
             s.close()
     except AssertionError as e:
