@@ -27,6 +27,15 @@ renders all its strips in one launch into device memory and rank 0 gathers them 
 indices into a float3 accumulator; rank 0 gathers and adds them in rank order.  The frame is fixed,
 so scaling is "strong".
 
+The default line also carries `configs`: every BASELINE config measured in the same run, each with its own steps / ms_per_step /
+roofline / bounded cpu_baseline - C1 (configs[0], 400x225x16), C2 (the headline itself), C3 (the target scene), C4 (configs[3]:
+mesh_demo 4K at the full 1024 spp, tile mode) and C5 (configs[4]: the 9.99 M-triangle instanced scene at 4K, spp mode: timed
+at 64 spp, plus ONE step at the full 4096 spp).  Their step counts are fixed and small (a C5 frame at 4096 spp is 10 s on one
+GPU) and do not follow --steps / --warmup; `--no-extra-configs` leaves them out.
+
+The timed step writes the float3 frame (the V3 of cast_rays_into_scene); the RGBA8 conversion of src/rgba.rs is the same
+finish_kernel with a second store (9 us per 1080p frame) and is exercised by the tests, not timed here (`writes`: "float3").
+
 The JSON line also carries
   roofline     : the render kernel against the f32 VALU peak (the path is f32 vector arithmetic +
                  latency bound; no MFMA: not a dense contraction; scenes are cache resident so HBM
@@ -34,6 +43,9 @@ The JSON line also carries
                  follow SURVEY.md 8(d): per-ray node / primitive / transform counts of an ordered,
                  t_max-shrinking traversal, measured by the oracle on a sample of the same frame,
                  times fixed per-op costs.
+                 `counter_frac` beside `frac`: the same fraction from the hardware counter instead of the model -
+                 SQ_INSTS_VALU_FLOPS_FP32 (wave instructions) x 64 x lane utilisation per ray, from the committed rocprofv3 --pmc
+                 pass of the workload (profiles/pmc_counters.json), x this run's rays per second / peak.
   cpu_baseline : the oracle's restatement of the reference's multithreaded CPU path (kind "port";
                  the Rust reference cannot be built: no rustc), timed on this box's host cores on a
                  bounded sample of the same frame: median of 3 runs with 16 threads (the reference
@@ -68,6 +80,15 @@ WORKLOADS = {
     "dootdoot-4k-64spp": ("Doot Doot", 3840, 2160, 64, 8, 0.1, {"Count": 30, "Spacing": 30}),  # configs[4] geometry
     "dootdoot-4k-4096spp": ("Doot Doot", 3840, 2160, 4096, 8, 0.1, {"Count": 30, "Spacing": 30}),  # configs[4] in full (~12 s per frame on one GPU)
 }
+# the BASELINE configs beside the headline and the target scene: (key, workload, mode, reduce, steps, warmup, cpu baseline?, same scene as)
+EXTRA_CONFIGS = [
+    ("C1", "weekend-400x225-16spp", "tiles", "ordered", 5, 1, True),
+    ("C4", "meshdemo-4k-1024spp", "tiles", "ordered", 2, 1, True),
+    ("C5", "dootdoot-4k-64spp", "spp", "allreduce", 2, 1, True),
+    ("C5_full", "dootdoot-4k-4096spp", "spp", "allreduce", 1, 0, False),
+]
+# PMC passes are collected on the 64-spp frames of the 4K scenes: per-ray counters do not depend on the sample count
+PMC_WORKLOAD = {"meshdemo-4k-1024spp": "meshdemo-4k-64spp", "dootdoot-4k-4096spp": "dootdoot-4k-64spp"}
 HEADLINE = "weekend-1080p-256spp"
 TARGET_SCENE = "dreadnaught-1080p-128spp"
 SEED = 12345
@@ -84,6 +105,7 @@ def parse_args(argv=None):
                     help="--mode spp: gather + sum in rank order on rank 0 (deterministic), or one RCCL all-reduce")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle legs (roofline statistics and CPU baseline)")
     ap.add_argument("--no-target-scene", action="store_true", help="do not also time the target scene (configs[2])")
+    ap.add_argument("--no-extra-configs", action="store_true", help="do not also time BASELINE configs C1, C4 and C5 (the `configs` object)")
     ap.add_argument("--launcher", action="store_true", help="go through torch.distributed.run even for --gpus 1 (rehearsal of the N > 1 path)")
     ap.add_argument("--cpu-seconds", type=float, default=4.0, help="CPU work per baseline run (3 runs per thread count)")
     return ap.parse_args(argv)
@@ -109,9 +131,15 @@ def launch_ranks(args):
     sys.exit(subprocess.run(cmd, env=env).returncode)
 
 
-def measure(workload, args, ctx):
-    """Times args.steps render passes of one workload on this rank's GPU (all ranks together); returns the
+def measure(workload, args, ctx, mode=None, reduce=None, steps=None, warmup=None):
+    """Times `steps` (default args.steps) render passes of one workload on this rank's GPU (all ranks together); returns the
     fields of the JSON line on rank 0 (None elsewhere) plus what the oracle legs need."""
+    import types
+    args = types.SimpleNamespace(**vars(args))
+    if mode is not None: args.mode = mode
+    if reduce is not None: args.reduce = reduce
+    if steps is not None: args.steps = steps
+    if warmup is not None: args.warmup = warmup
     import torch
     from raytracer_amd import CameraConfiguration, RenderChunk, RenderSettings, Scene, SceneBuilder, resolve_device
     from raytracer_amd.dist import InterleavedCompositor, reduce_accumulators, sample_range_of_rank
@@ -195,11 +223,11 @@ def measure(workload, args, ctx):
                    "entities": int(info.entity_count), "triangles": int(info.instanced_triangle_count),
                    "mode": args.mode, "parallelism": parallelism},
         "rccl_ranks": ctx["world"] if dist is not None else 0,
-        "msamples_per_s": round(samples / elapsed / 1e6, 3),
+        "msamples_per_s": round(samples / elapsed / 1e6, 3), "writes": "float3",
         "rays_per_step": {"primary": primary // args.steps, "secondary": secondary // args.steps, "shadow": shadow // args.steps},
     }
     return dict(line=line, builder=builder, settings=settings, info=info, kernel_ms=kernel_ms, launches=launches, local_rays=local_rays,
-                W=W, H=H, spp=spp, depth=depth, workload=workload)
+                W=W, H=H, spp=spp, depth=depth, workload=workload, steps=args.steps)
 
 
 def host_threads():
@@ -216,8 +244,9 @@ def host_threads():
     return max(1, allowed)
 
 
-def oracle_legs(m, args, n_gpus):
+def oracle_legs(m, args, n_gpus, cpu_leg=True, cpu_seconds=None):
     """Rank 0: roofline statistics of the render kernel (any N) and the CPU baseline (N = 1)."""
+    cpu_seconds = args.cpu_seconds if cpu_seconds is None else cpu_seconds
     from raytracer_amd import RenderSettings, sample_segment
     from tests.oracle import ORC_RNG_COUNTER_STRATIFIED, ORC_RNG_XORSHIFT_CHUNK, OracleScene
     line, W, H, spp, depth, info = m["line"], m["W"], m["H"], m["spp"], m["depth"], m["info"]
@@ -246,7 +275,7 @@ def oracle_legs(m, args, n_gpus):
     tflops = flops_per_ray * rays_per_launch / kernel_s / 1e12
     # algorithmic HBM bytes of one launch: the scene once + one float3 segment sum per work item
     segs = (spp + sample_segment() - 1) // sample_segment()
-    hbm_bytes_per_launch = (int(info.device_bytes) + W * H * segs * B_PIXEL // n_gpus) * (args.steps / launches)
+    hbm_bytes_per_launch = (int(info.device_bytes) + W * H * segs * B_PIXEL // n_gpus) * (m["steps"] / launches)
     gbs = hbm_bytes_per_launch / kernel_s / 1e9
     traffic = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # HBM bytes per launch from rocprofv3 --pmc passes
@@ -255,9 +284,32 @@ def oracle_legs(m, args, n_gpus):
             traffic = json.load(open(pmc_path)).get(m["workload"])
         except Exception:
             traffic = None
+    # the same fraction from the hardware counter of the committed PMC pass (executed lane-flops per ray x this run's ray rate)
+    counter_frac = counter_flops_per_ray = None
+    pmc_key = PMC_WORKLOAD.get(m["workload"], m["workload"])
+    cnt_path = os.path.join(ROOT, "profiles", "pmc_counters.json")
+    if os.path.exists(cnt_path) and n_gpus == 1:
+        try:
+            c = json.load(open(cnt_path)).get(pmc_key)
+            if c:
+                counter_flops_per_ray = c["valu_flops_fp32_wave_instr"] * 64.0 * c["lane_util"] / c["rays_per_launch"]
+                counter_frac = counter_flops_per_ray * rays_per_launch / kernel_s / 1e12 / VALU_PEAK_TFLOPS
+        except Exception:
+            counter_frac = counter_flops_per_ray = None
+    if traffic is not None and pmc_key != m["workload"]:
+        traffic = None
+    if traffic is None and os.path.exists(pmc_path) and n_gpus == 1 and pmc_key != m["workload"]:
+        try:          # per-launch bytes of the 64-spp frame, scaled to this launch's rays (the traffic is the segment sums and per-ray spills)
+            t64 = json.load(open(pmc_path)).get(pmc_key)
+            r64 = json.load(open(cnt_path)).get(pmc_key, {}).get("rays_per_launch")
+            traffic = int(t64 * rays_per_launch / r64) if t64 and r64 else None
+        except Exception:
+            traffic = None
     line["roofline"] = {
         "bound": "valu", "achieved": round(tflops, 4), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
         "frac": round(tflops / VALU_PEAK_TFLOPS, 5), "traffic": traffic,
+        "counter_frac": None if counter_frac is None else round(counter_frac, 5),
+        "counter_flops_per_ray": None if counter_flops_per_ray is None else round(counter_flops_per_ray, 2),
         "kernel": "render_kernel", "kernel_ms_avg": round(kernel_s * 1e3, 4), "launches": int(m["launches"]),
         "flops_per_ray": round(flops_per_ray, 2),
         "per_ray": {k: round(v, 3) for k, v in per_ray.items()}, "traversal_mismatch": int(cn_s.min_mismatch),
@@ -267,11 +319,11 @@ def oracle_legs(m, args, n_gpus):
                             "scene_bytes": int(info.device_bytes),
                             "on_chip_gather_bytes_per_ray": round(gather_bytes_per_ray, 2),
                             "on_chip_gather_GBps": round(gather_bytes_per_ray * rays_per_launch / kernel_s / 1e9, 1)}
-    if n_gpus != 1:
+    if n_gpus != 1 or not cpu_leg:
         return
     # (2) the reference's multithreaded CPU path on a bounded sample of the same frame: chunks spread evenly over the
     # frame, full spp, per-chunk XorShift RNG; about args.cpu_seconds of work per run, 3 runs per thread count, median.
-    target = min(3.0e8, max(1.0e6, cpu_samples_per_s * args.cpu_seconds))
+    target = min(3.0e8, max(1.0e6, cpu_samples_per_s * cpu_seconds))
     stride = max(1, int(round(W * H * spp / target)))
     if stride > 4:          # a sparse sample: many small chunks spread over the frame instead of a few large ones
         grid = (128, 128)
@@ -338,16 +390,35 @@ def main():
     target = None
     if not args.no_target_scene and args.workload == HEADLINE:
         target = measure(TARGET_SCENE, args, ctx)
+    extras = []
+    if not args.no_extra_configs and args.workload == HEADLINE:
+        for key, workload, mode, reduce, steps, warmup, cpu_leg in EXTRA_CONFIGS:
+            extras.append((key, cpu_leg, measure(workload, args, ctx, mode=mode, reduce=reduce, steps=steps, warmup=warmup)))
     if rank == 0:
         if not args.no_cpu_baseline:
             oracle_legs(m, args, world)
             if target is not None:
                 oracle_legs(target, args, world)
+            for key, cpu_leg, e in extras:
+                oracle_legs(e, args, world, cpu_leg=cpu_leg, cpu_seconds=min(args.cpu_seconds, 2.0))
         result = m["line"]
+        keep = ("value", "unit", "steps", "warmup", "ms_per_step", "config", "msamples_per_s", "rays_per_step", "roofline", "roofline_hbm", "cpu_baseline",
+                "gpu_over_cpu")
         if target is not None:
             t = target["line"]
-            result["target_scene"] = {k: t[k] for k in ("value", "unit", "ms_per_step", "config", "msamples_per_s", "rays_per_step", "roofline",
-                                                         "roofline_hbm", "cpu_baseline", "gpu_over_cpu") if k in t}
+            result["target_scene"] = {k: t[k] for k in keep if k in t}
+        if extras:
+            # every BASELINE config in one line: C2 and C3 are the headline and the target scene above
+            cfgs = {"C2": {"see": "the top level of this line", "workload": HEADLINE}}
+            if target is not None:
+                cfgs["C3"] = {"see": "target_scene", "workload": TARGET_SCENE}
+            for key, cpu_leg, e in extras:
+                cfgs[key] = {k: e["line"][k] for k in keep if k in e["line"]}
+            c5, c5f = cfgs.get("C5"), cfgs.get("C5_full")
+            if c5 and c5f and "cpu_baseline" in c5:        # Mrays/s of the CPU path do not depend on the sample count: one CPU leg for both
+                c5f["gpu_over_cpu"] = round(c5f["value"] / c5["cpu_baseline"]["value"], 1)
+                c5f["cpu_baseline"] = {"see": "configs.C5.cpu_baseline (same scene and frame; the CPU rate does not depend on the sample count)"}
+            result["configs"] = cfgs
         print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()

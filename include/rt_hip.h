@@ -49,6 +49,8 @@ extern "C" {
                                 (which only enqueue) for every LATER call on the scene */
 #define RT_E_IO         -5   /* file could not be read (sample scenes / OBJ)    */
 #define RT_E_LIMIT      -6   /* size beyond a documented maximum                */
+#define RT_E_CANCELLED  -7   /* rt_scene_cancel was called: the call ended early
+                                (or was refused), output pixels are unfinished   */
 
 /* ---- POD vector types (types.rs:11-12, :254-255) ------------------------ */
 typedef struct RtV3 { float x, y, z; } RtV3;
@@ -259,8 +261,11 @@ int rt_scene_update_transforms(RtScene* scene, const RtV3* translations, uint64_
  * the build) and rt_scene_bvh_order(-1) still reports the tree of rt_scene_create.  The first call allocates
  * (about 150 bytes per entity + 64 per entity of node records).  Enqueued on `stream`, then waits for it.  No render call
  * on this scene may be in flight.  RT_E_INVALID (nothing changed): some rotation axis is not of unit length - such an entity's box
- * does not bound its hits, and only the reference's own tree reproduces what the reference then reports.  RT_E_DEPTH: the new tree is deeper than the LDS traversal stack can hold (64 levels);
- * the scene must then be created anew. */
+ * does not bound its hits, and only the reference's own tree reproduces what the reference then reports.  RT_E_DEPTH: the new tree is deeper than the
+ * LDS traversal stack can hold (64 levels); RT_E_LIMIT: its records would exceed the 2^26 the walk addresses.  Both are found BEFORE anything a render
+ * call reads is written: a refused call leaves the scene - transforms, boxes, tree - exactly as it was (only rt_scene_update_transforms on a
+ * device-built tree is then refused until the next successful rebuild: the working buffers hold the refused topology).  A HIP failure after the
+ * commit has begun (none is expected) marks the scene unusable: every later call returns RT_E_HIP. */
 int rt_scene_rebuild_tlas(RtScene* scene, const RtV3* translations, uint64_t translation_count,
                           const RtRotation* rotations, uint64_t rotation_count, void* stream);
 
@@ -280,7 +285,10 @@ enum {
     RT_OPT_LENS_COC_PX = 4,
     /* tests of RT_E_DEPTH: run the kernels with a traversal stack of this many entries (0 = what the trees
      * need) and clear the scene's sticky overflow error.  Synchronises the device. */
-    RT_OPT_DEBUG_STACK_ENTRIES = 100
+    RT_OPT_DEBUG_STACK_ENTRIES = 100,
+    /* tests of rt_scene_rebuild_tlas's refusal: a rebuilt tree that needs more traversal-stack entries than this is refused
+     * with RT_E_DEPTH as if it exceeded the LDS limit (0 = the LDS limit only). */
+    RT_OPT_DEBUG_REBUILD_STACK_LIMIT = 101
 };
 int rt_scene_set_option(RtScene* scene, uint32_t option, double value);
 
@@ -363,6 +371,52 @@ int rt_accumulate_chunk_device(RtScene* scene, const RtSettings* settings,
                                const RtRenderChunk* chunk, uint64_t seed,
                                uint32_t sample_first, uint32_t sample_count,
                                void* accum_dev, void* counters_dev, void* stream);
+
+/* One frame on N GPUs, composited on the first.  Replaces the reference's pool of worker threads over one shared chunk
+ * queue (start_background_render_threads, src/render.rs:186-224; RenderJob::update's hand-out, :63-78) ACROSS devices, for
+ * a host that is one process (the egui front end): `scenes` are n_scenes replicas of the same scene, one RtScene per
+ * device (rt_scene_create(desc, device); two replicas may also share a device).  One host thread per replica enqueues
+ * that replica's share on a stream of its own; the call returns when the frame is complete in GPU 0's memory
+ * (GPU 0 = scenes[0]'s device; rgb_dev0 / rgba_dev0 are device pointers THERE, width * height pixels, either nullable).
+ *   RT_MULTI_TILES: 8-row strips dealt round-robin (replica i owns strips i, i + n, ...), every replica renders all its
+ *                   strips in one launch (rt_render_strips_device) and writes them straight into GPU 0's frame over its
+ *                   own xGMI link (peer access), or - where peer access is refused - packs them and copies strip by
+ *                   strip (hipMemcpyPeerAsync).  The frame is that of ONE rt_render_chunk_device call, bit for bit.
+ *   RT_MULTI_SPP  : every replica renders the whole frame for its range of whole sample segments into an accumulator
+ *                   (rt_accumulate_chunk_device); the accumulators are copied to GPU 0 and added there IN REPLICA ORDER,
+ *                   then resolved (rt_resolve_device).  Equal to the one-call frame up to the association of the final
+ *                   sums of segment sums (1 ulp-scale); bit-identical for a given n_scenes.
+ * `counters` (host, nullable) is ADDED to.  The streams, events and staging buffers are cached in scenes[0] and freed
+ * with it.  One frame at a time per process.  The same RtScene twice is RT_E_INVALID. */
+#define RT_MULTI_TILES 0
+#define RT_MULTI_SPP   1
+int rt_render_frame_multi(RtScene* const* scenes, uint32_t n_scenes, const RtSettings* settings,
+                          uint32_t mode, uint64_t seed, void* rgb_dev0, void* rgba_dev0,
+                          RtRayCounters* counters);
+
+/* The same frame into HOST buffers (the pair rt_render_chunk / rt_render_chunk_device again): what a host without a HIP
+ * allocator of its own - the egui front end wants RGBA bytes for its texture, src/job_running.rs:37-41 - calls.  The
+ * frame is rendered into buffers scenes[0] keeps on its device and copied out; rgb_out (width * height * 3 floats) and
+ * rgba_out (width * height * 4 bytes) are nullable. */
+int rt_render_frame_multi_host(RtScene* const* scenes, uint32_t n_scenes, const RtSettings* settings,
+                               uint32_t mode, uint64_t seed, float* rgb_out, uint8_t* rgba_out,
+                               RtRayCounters* counters);
+
+/* Cancellation and progress INSIDE a call.  The reference checks its cancellation token per work item and per pixel
+ * (src/render.rs:131,149) and sends a snapshot of the chunk every 800 ms (:146,156-158); a GPU call of seconds (a 4K frame
+ * at 4096 spp runs 10 s) needs the same two things from another host thread.
+ *   rt_scene_cancel(scene, 1): every launch on the scene - running or enqueued - stops handing out work: a wave reads the
+ *     scene's host-mapped cancel word at its first and then every 4th block claim, so a running kernel drains within a few
+ *     blocks per wave (milliseconds).  The blocking entry points (rt_render_chunk, rt_render_frame_multi) then return
+ *     RT_E_CANCELLED; enqueue-only entry points return it for calls made while the scene is cancelled.  Output pixels of a
+ *     cancelled call are unfinished.  The scene stays usable: rt_scene_cancel(scene, 0) re-arms it (call it once the
+ *     cancelled work has drained - after the blocking call returned, or after synchronising the stream).
+ *   rt_scene_progress: blocks_total = 64-ray-tile x sample-unit blocks of the call in flight on this scene (all its
+ *     launches), blocks_done = about how many of them have been handed out (written by the waves at their poll points;
+ *     an estimate that only grows within a launch).  Reads host memory only: callable at any time from any thread.
+ *     With several calls in flight on one scene the numbers are those of the latest. */
+int rt_scene_cancel(RtScene* scene, int cancel);
+int rt_scene_progress(const RtScene* scene, uint64_t* blocks_done, uint64_t* blocks_total);
 
 /* Finishes an accumulator: rgb = accum / spp (implementation.rs:659) and
  * rgba = v3_to_rgba(rgb) (src/rgba.rs:6-12) for n_pixels pixels. Device pointers;

@@ -18,6 +18,10 @@ pub const RT_E_NO_DEVICE: c_int = -3;
 pub const RT_E_DEPTH: c_int = -4;
 pub const RT_E_IO: c_int = -5;
 pub const RT_E_LIMIT: c_int = -6;
+pub const RT_E_CANCELLED: c_int = -7;
+
+pub const RT_MULTI_TILES: u32 = 0;
+pub const RT_MULTI_SPP: u32 = 1;
 
 pub const RT_HITABLE_SPHERE: u32 = 0;
 pub const RT_HITABLE_PLANE: u32 = 1;
@@ -49,6 +53,7 @@ pub const RT_OPT_FINE_SPLIT: u32 = 2;
 pub const RT_OPT_ROUND_UNITS: u32 = 3;
 pub const RT_OPT_LENS_COC_PX: u32 = 4;
 pub const RT_OPT_DEBUG_STACK_ENTRIES: u32 = 100;
+pub const RT_OPT_DEBUG_REBUILD_STACK_LIMIT: u32 = 101;
 
 #[repr(C)]
 #[derive(Clone, Copy, Debug, Default, PartialEq)]
@@ -272,6 +277,10 @@ extern "C" {
     pub fn rt_render_strips_device(scene: *mut RtScene, settings: *const RtSettings, strip_height: u32, strip_first: u32, strip_period: u32, seed: u64, rgb_dev: *mut c_void, rgba_dev: *mut c_void, counters_dev: *mut c_void, stream: *mut c_void) -> c_int;
     pub fn rt_strip_rows(height: u32, strip_height: u32, strip_first: u32, strip_period: u32) -> c_int;
     pub fn rt_accumulate_chunk_device(scene: *mut RtScene, settings: *const RtSettings, chunk: *const RtRenderChunk, seed: u64, sample_first: u32, sample_count: u32, accum_dev: *mut c_void, counters_dev: *mut c_void, stream: *mut c_void) -> c_int;
+    pub fn rt_render_frame_multi(scenes: *const *mut RtScene, n_scenes: u32, settings: *const RtSettings, mode: u32, seed: u64, rgb_dev0: *mut c_void, rgba_dev0: *mut c_void, counters: *mut RtRayCounters) -> c_int;
+    pub fn rt_render_frame_multi_host(scenes: *const *mut RtScene, n_scenes: u32, settings: *const RtSettings, mode: u32, seed: u64, rgb_out: *mut f32, rgba_out: *mut u8, counters: *mut RtRayCounters) -> c_int;
+    pub fn rt_scene_cancel(scene: *mut RtScene, cancel: c_int) -> c_int;
+    pub fn rt_scene_progress(scene: *const RtScene, blocks_done: *mut u64, blocks_total: *mut u64) -> c_int;
     pub fn rt_resolve_device(device: c_int, accum_dev: *const c_void, n_pixels: u64, samples_per_pixel: u32, rgb_dev: *mut c_void, rgba_dev: *mut c_void, stream: *mut c_void) -> c_int;
     pub fn rt_primary_hits(scene: *mut RtScene, settings: *const RtSettings, chunk: *const RtRenderChunk, t_out: *mut f32, normal_out: *mut f32, entity_out: *mut i32, tri_out: *mut i32) -> c_int;
     pub fn rt_create_render_chunks(width: u32, height: u32, count_x: u32, count_y: u32, out: *mut RtRenderChunk, capacity: u32) -> c_int;
@@ -368,9 +377,44 @@ impl GpuScene {
         })
     }
 
+    /// The cancellation token of `src/render.rs:131,149` reaching INTO a running call: every launch on the scene stops handing
+    /// out work, the blocked `render_chunk_rgba` returns `RT_E_CANCELLED` within milliseconds.  `cancel(false)` re-arms the scene.
+    pub fn cancel(&self, cancel: bool) -> Result<(), GpuError> {
+        check(unsafe { rt_scene_cancel(self.handle, if cancel { 1 } else { 0 }) })
+    }
+
+    /// (blocks handed out so far - an estimate -, blocks of the call in flight): what the 800 ms snapshot of
+    /// `src/render.rs:156-158` becomes when the pixel loop is one GPU call.
+    pub fn progress(&self) -> Result<(u64, u64), GpuError> {
+        let (mut done, mut total) = (0u64, 0u64);
+        check(unsafe { rt_scene_progress(self.handle, &mut done, &mut total) })?;
+        Ok((done, total))
+    }
+
     pub fn as_ptr(&self) -> *mut RtScene {
         self.handle
     }
+}
+
+/// One frame on several GPUs, composited in the first replica's device memory (`rt_render_frame_multi`): the worker-thread
+/// pool of `src/render.rs:186-224` across devices.  `replicas[i]` is the same scene created on device i.
+/// The same frame as RGBA8 bytes on the host (what `job_running.rs:37-41` blits into the egui texture).
+pub fn render_frame_multi_rgba(replicas: &[&GpuScene], settings: &RtSettings, mode: u32, seed: u64, rgba: &mut [u8]) -> Result<RtRayCounters, GpuError> {
+    let need = settings.width as usize * settings.height as usize * 4;
+    if rgba.len() < need {
+        return Err(GpuError { code: RT_E_INVALID, message: format!("rgba buffer holds {} bytes, the frame needs {}", rgba.len(), need) });
+    }
+    let handles: Vec<*mut RtScene> = replicas.iter().map(|s| s.as_ptr()).collect();
+    let mut counters = RtRayCounters::default();
+    check(unsafe { rt_render_frame_multi_host(handles.as_ptr(), handles.len() as u32, settings, mode, seed, std::ptr::null_mut(), rgba.as_mut_ptr(), &mut counters) })?;
+    Ok(counters)
+}
+
+pub fn render_frame_multi(replicas: &[&GpuScene], settings: &RtSettings, mode: u32, seed: u64, rgb_dev0: *mut c_void, rgba_dev0: *mut c_void) -> Result<RtRayCounters, GpuError> {
+    let handles: Vec<*mut RtScene> = replicas.iter().map(|s| s.as_ptr()).collect();
+    let mut counters = RtRayCounters::default();
+    check(unsafe { rt_render_frame_multi(handles.as_ptr(), handles.len() as u32, settings, mode, seed, rgb_dev0, rgba_dev0, &mut counters) })?;
+    Ok(counters)
 }
 
 impl Drop for GpuScene {

@@ -13,7 +13,8 @@ REPO_ROOT = os.path.dirname(_HERE)
 ASSET_MESH_DIR = os.path.join(REPO_ROOT, "assets", "meshes")
 
 RT_ABI_VERSION = 1
-RT_OK, RT_E_INVALID, RT_E_HIP, RT_E_NO_DEVICE, RT_E_DEPTH, RT_E_IO, RT_E_LIMIT = 0, -1, -2, -3, -4, -5, -6
+RT_OK, RT_E_INVALID, RT_E_HIP, RT_E_NO_DEVICE, RT_E_DEPTH, RT_E_IO, RT_E_LIMIT, RT_E_CANCELLED = 0, -1, -2, -3, -4, -5, -6, -7
+RT_MULTI_TILES, RT_MULTI_SPP = 0, 1
 
 RT_HITABLE_SPHERE, RT_HITABLE_PLANE, RT_HITABLE_MESH = 0, 1, 2
 RT_MAT_LAMBERTIAN, RT_MAT_SPECULAR, RT_MAT_DIELECTRIC = 0, 1, 2
@@ -24,6 +25,7 @@ RT_SKY_DAY, RT_SKY_BLACK = 0, 1
 RT_DEVICE_HOST_ONLY = -1
 # rt_scene_set_option
 RT_OPT_LENS_SAMPLER, RT_OPT_FINE_SPLIT, RT_OPT_ROUND_UNITS, RT_OPT_LENS_COC_PX, RT_OPT_DEBUG_STACK_ENTRIES = 1, 2, 3, 4, 100
+RT_OPT_DEBUG_REBUILD_STACK_LIMIT = 101
 
 
 class RtV3(C.Structure):
@@ -180,6 +182,12 @@ HIP_PROTOTYPES = {
     "rt_scene_update_transforms": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p]),
     "rt_scene_rebuild_tlas": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p]),
     "rt_scene_profile_read": (C.c_int, [C.c_void_p, _P(C.c_double), _P(C.c_uint64)]),
+    "rt_render_frame_multi": (C.c_int, [_P(C.c_void_p), C.c_uint32, _P(RtSettings), C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p,
+                                        _P(RtRayCounters)]),
+    "rt_render_frame_multi_host": (C.c_int, [_P(C.c_void_p), C.c_uint32, _P(RtSettings), C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p,
+                                             _P(RtRayCounters)]),
+    "rt_scene_cancel": (C.c_int, [C.c_void_p, C.c_int]),
+    "rt_scene_progress": (C.c_int, [C.c_void_p, _P(C.c_uint64), _P(C.c_uint64)]),
 }
 
 SAMPLES_PROTOTYPES = {

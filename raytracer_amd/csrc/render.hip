@@ -34,6 +34,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -55,6 +56,9 @@
 #define RT_QUEUES 16u            /* block counters per launch, one cache line each */
 #endif
 #define RT_MAX_REFLECTIONS 31u
+#ifndef RT_CANCEL_POLL
+#define RT_CANCEL_POLL 4u        /* a wave reads the cancel word at every 4th block claim (power of two) */
+#endif
 #ifdef RT_PHASE_TIME            /* (make time: a flavour of the diagnostics build) */
 #define RT_PHASE_STATS
 #endif
@@ -128,6 +132,7 @@ __device__ __forceinline__ Word4 ldw(const Word4* p) {
 // out too small.  Never expected; reported as RT_E_DEPTH instead of a silently wrong image.
 #define RT_DEVERR_STACK   1u      /* traversal stack full: a deferred subtree would have been dropped */
 #define RT_DEVERR_PENDING 2u      /* deferred-ray list full: a refraction ray would have been dropped */
+#define RT_DEVERR_POISONED 4u     /* set by the HOST: a call failed after it had begun to rewrite the scene's device data (rt_scene_rebuild_tlas) */
 
 // ===========================================================================
 // counter-based RNG: Philox4x32-10 (Random123), counter = (x | y<<16, sample,
@@ -293,7 +298,7 @@ __device__ __forceinline__ void trace(const DevSceneView& S, const F3 wo, const 
                 for (int c = 3; c >= 1; c--)
                     if (hits > (uint32_t)c) {
                         if (sp < stack_cap) stack[(sp++) * RT_BLOCK] = r4[c];
-                        else *error_flag = RT_DEVERR_STACK;
+                        else atomicOr(error_flag, RT_DEVERR_STACK);
                     }
                 cur = r4[0];
                 continue;
@@ -308,7 +313,7 @@ __device__ __forceinline__ void trace(const DevSceneView& S, const F3 wo, const 
                 const uint32_t far_ref = left_first ? r.u[1] : r.u[0];
                 cur = left_first ? r.u[0] : r.u[1];
                 if (sp < stack_cap) stack[(sp++) * RT_BLOCK] = far_ref;
-                else *error_flag = RT_DEVERR_STACK;
+                else atomicOr(error_flag, RT_DEVERR_STACK);
             } else if (hl || hr) cur = hl ? r.u[0] : r.u[1];
             else cur = pop();
         }
@@ -402,7 +407,7 @@ __device__ __forceinline__ void trace(const DevSceneView& S, const F3 wo, const 
                 if (slab(m1.f[0], m1.f[1], m1.f[2], m1.f[3], m2.f[0], m2.f[1], eo, einv, t_min, best_t, e)) {      // entity space: exact box
                     if (k + 1 < count) {
                         if (sp < stack_cap) stack[(sp++) * RT_BLOCK] = RT_REF_LEAF_BIT | ((count - k - 2) << RT_REF_COUNT_SHIFT) | (ei + 1);
-                        else *error_flag = RT_DEVERR_STACK;
+                        else atomicOr(error_flag, RT_DEVERR_STACK);
                     }
                     inst_sp = sp;
                     o = eo; d = ed; inv = einv;
@@ -616,6 +621,9 @@ struct RenderParams {
     uint32_t lens_rounds;                           // tiles flagged by classify_kernel may run rounds of one sample index (8 units x 8 pixels)
     uint32_t lens_stratify;                         // 1: stratified lens samples (the product's sampler); 0: two independent draws (implementation.rs:648-653)
     uint32_t* error_flag;                           // sticky device-side error word (RT_DEVERR_* bits), read back by the host entry points
+    const uint32_t* cancel_word;                    // host-mapped: non-zero = rt_scene_cancel; the waves stop claiming blocks (src/render.rs:131,149: the cancellation token)
+    uint32_t* progress_word;                        // host-mapped: about how many blocks of the call have been handed out so far (rt_scene_progress)
+    uint32_t progress_base;                         // blocks of the call's earlier launches
     uint32_t tiles_x, pix_slots;                    // 8x8 tiling of the chunk; pix_slots = tiles*64
     float* partial;                                 // [unit_count][tile][64][3] sums of the clamped samples of each unit (8x8 tiles of the chunk)
     unsigned long long* counters;                   // RtRayCounters on the device (nullable)
@@ -710,6 +718,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
 
     uint32_t n_primary = 0, n_secondary = 0, n_shadow = 0, n_samples = 0;
     uint32_t queue = (blockIdx.x * (RT_BLOCK / 64u) + (threadIdx.x >> 6)) % RT_QUEUES;      // this wave's current block counter
+    uint32_t claims = 0;                                                                    // (wave-uniform) block claims of this wave so far
 #if defined(RT_PHASE_STATS) && !defined(RT_PHASE_TIME)
     uint32_t ph_lanes[PH_COUNT] = {}, ph_waves[PH_COUNT] = {};
 #endif
@@ -766,13 +775,26 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                 // next one when that is exhausted, so the hand-out order stays "expensive first".
                 const uint32_t total_blocks = total_items >> 6;          // pix_slots is a multiple of 64
                 uint32_t blk = total_blocks;
-                for (uint32_t tries = 0; tries < RT_QUEUES && blk >= total_blocks; tries++) {
+                // Cancellation (the reference checks its token per work item and per pixel, src/render.rs:131,149): every RT_CANCEL_POLL-th claim of a
+                // wave - and its first - lane 0 reads the scene's host-mapped cancel word (one uncached read over the host link, hidden behind the
+                // other waves of the SIMD); a cancelled wave claims nothing more, so the launch drains within one block per wave.
+                bool polled = false, cancelled = false;
+                if ((claims++ & (RT_CANCEL_POLL - 1u)) == 0u) {
+                    uint32_t c = 0;
+                    if (lane == 0) c = __hip_atomic_load(P.cancel_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    cancelled = __builtin_amdgcn_readfirstlane(c) != 0u;
+                    polled = true;
+                }
+                for (uint32_t tries = 0; tries < RT_QUEUES && blk >= total_blocks && !cancelled; tries++) {
                     uint32_t idx = 0;
                     if (lane == 0) idx = atomicAdd(P.block_counter + queue * 16u, 1u);
                     idx = __builtin_amdgcn_readfirstlane(idx);
                     blk = idx < (total_blocks + RT_QUEUES - 1u) / RT_QUEUES ? idx * RT_QUEUES + queue : total_blocks;      // (guards the multiply)
                     if (blk >= total_blocks) { blk = total_blocks; queue = (queue + 1u) % RT_QUEUES; }
                 }
+                // progress (src/render.rs:156-158 sends a snapshot every 800 ms): the queues advance evenly, so the number of the block just claimed
+                // is about the number of blocks handed out; plain stores, last writer wins - an estimate, not a count
+                if (polled && lane == 0 && blk < total_blocks) __hip_atomic_store(P.progress_word, P.progress_base + blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 if (blk >= total_blocks) state = FINISHED;
                 else {
                     // Block numbering: first every unit of each tile whose rays hit something, tile after
@@ -902,7 +924,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                         if (refract_limit == 0u) sample_col = sample_col + (cw_ * color_sky(S, refr_d));   // :562-564
                         else if (!(cast_refl && reflect_limit != 0u)) refr_in_place = true;
                         else if (npend < RT_PENDING_MAX) { Pending& q = pend[npend++]; q.o = hr.p; q.d = refr_d; q.w = cw_; q.limit = refract_limit; q.node = parent * 2u + 1u; }
-                        else *P.error_flag = RT_DEVERR_PENDING;
+                        else atomicOr(P.error_flag, RT_DEVERR_PENDING);
                     }
                     if (cast_refl) {
                         const F3 cw_ = wa * reflection_intensity;
@@ -1090,7 +1112,17 @@ render_kernel(const DevSceneView S, const RenderParams P) {
             if (sp == 0) return RT_NONE;
             return stack[(--sp) * RT_BLOCK];
         };
+#if defined(RT_PHASE_STATS) && !defined(RT_PHASE_TIME)
+        // per burst: which kinds of ray it holds (bit 0 camera rays, 1 secondary path rays, 2 shadow rays), how many lanes start, iterations, lane-iterations
+        const uint32_t bk_kind = (__ballot(tracing && state == PATH && rnode == 1u) ? 1u : 0u) | (__ballot(tracing && state == PATH && rnode != 1u) ? 2u : 0u) |
+                                 (__ballot(tracing && state == SHADOW) ? 4u : 0u);
+        const uint32_t bk_start = (uint32_t)__popcll(__ballot(tracing));
+        uint32_t bk_iters = 0, bk_lane_iters = 0;
+#endif
         for (;;) {
+#if defined(RT_PHASE_STATS) && !defined(RT_PHASE_TIME)
+            bk_iters++; bk_lane_iters += (uint32_t)__popcll(__ballot(tracing));
+#endif
             if (tracing) {
                 PH(PH_BURST);
                 TM(TM_NODE);
@@ -1116,7 +1148,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                         const uint32_t far_ref = left_first ? nr.u[1] : nr.u[0];
                         cur = left_first ? nr.u[0] : nr.u[1];
                         if (sp < stack_cap) stack[(sp++) * RT_BLOCK] = far_ref;
-                        else *P.error_flag = RT_DEVERR_STACK;
+                        else atomicOr(P.error_flag, RT_DEVERR_STACK);
                     } else if (hl || hr) cur = hl ? nr.u[0] : nr.u[1];
                     else cur = pop();
                 }
@@ -1230,7 +1262,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                                 if (slab(m1.f[0], m1.f[1], m1.f[2], m1.f[3], m2.f[0], m2.f[1], eo, einv, t_min, best_t, e)) {
                                     if (k + 1 < count) {
                                         if (sp < stack_cap) stack[(sp++) * RT_BLOCK] = RT_REF_LEAF_BIT | ((count - k - 2) << RT_REF_COUNT_SHIFT) | (ei + 1);
-                                        else *P.error_flag = RT_DEVERR_STACK;
+                                        else atomicOr(P.error_flag, RT_DEVERR_STACK);
                                     }
                                     inst_sp = sp;
                                     o = eo; d = ed; inv = einv;
@@ -1262,6 +1294,12 @@ render_kernel(const DevSceneView S, const RenderParams P) {
             if (busy == 0ull) break;          // synchronous: the burst ends when every ray of the wave has ended
 #endif
         }
+#if defined(RT_PHASE_STATS) && !defined(RT_PHASE_TIME)
+        if (lane == 0) {
+            unsigned long long* b = P.phase_stats + 2 * PH_COUNT + 4 * bk_kind;
+            atomicAdd(b, 1ull); atomicAdd(b + 1, (unsigned long long)bk_start); atomicAdd(b + 2, (unsigned long long)bk_iters); atomicAdd(b + 3, (unsigned long long)bk_lane_iters);
+        }
+#endif
     }
 
 #ifdef RT_PHASE_TIME
@@ -1325,14 +1363,18 @@ __device__ __forceinline__ uint8_t f32_as_u8(float f) {      // Rust `as u8`: tr
 
 // col / spp (implementation.rs:659) and v3_to_rgba (src/rgba.rs:6-12).
 // Source: acc image (pitch src_pitch, origin sx,sy); destination images (pitch dst_pitch, origin dx,dy).
+// strip_h != 0: the source rows are one rank's packed strips and go to their image rows (strip k of the rank = rows first_row + k * period_rows ...):
+// the destination may then be the frame on ANOTHER device (rt_render_frame_multi writes each GPU's strips straight into GPU 0's frame over xGMI).
 __global__ void finish_kernel(const float* acc, uint32_t src_pitch, uint32_t sx, uint32_t sy, uint32_t cw, uint32_t npix, float spp,
-                              float* rgb, uint8_t* rgba, uint32_t dst_pitch, uint32_t dx, uint32_t dy) {
+                              float* rgb, uint8_t* rgba, uint32_t dst_pitch, uint32_t dx, uint32_t dy,
+                              uint32_t strip_h = 0u, uint32_t period_rows = 0u, uint32_t first_row = 0u) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= npix) return;
     const uint32_t x = i % cw, y = i / cw;
     const float* a = acc + ((uint64_t)(sy + y) * src_pitch + sx + x) * 3;
     const float r = a[0] / spp, g = a[1] / spp, b = a[2] / spp;
-    const uint64_t o = (uint64_t)(dy + y) * dst_pitch + dx + x;
+    const uint32_t row = strip_h ? first_row + (y / strip_h) * period_rows + (y % strip_h) : dy + y;
+    const uint64_t o = (uint64_t)row * dst_pitch + dx + x;
     if (rgb) { rgb[o * 3] = r; rgb[o * 3 + 1] = g; rgb[o * 3 + 2] = b; }
     if (rgba) { rgba[o * 4] = f32_as_u8(255.0f * r); rgba[o * 4 + 1] = f32_as_u8(255.0f * g); rgba[o * 4 + 2] = f32_as_u8(255.0f * b); rgba[o * 4 + 3] = 255; }
 }
@@ -1347,8 +1389,9 @@ __global__ void finish_kernel(const float* acc, uint32_t src_pitch, uint32_t sx,
 // Measured on weekend 1080p x 256 spp, per-rank time of the 8-rank strip partition:
 // 7.5-8.0 ms row-major, 6.2-6.5 ms ordered (ideal 6.1); Dreadnaught on one GPU 19.97 -> 19.08 ms.
 #define RT_COST_BINS 4u
+#define RT_ORDER_GROUP 1024u      /* tiles per block of order_kernel; classify_kernel counts the classes per such group */
 __global__ void __launch_bounds__(RT_BLOCK)
-classify_kernel(const DevSceneView S, const RenderParams P, uint32_t n_tiles, uint32_t* tile_bin) {
+classify_kernel(const DevSceneView S, const RenderParams P, uint32_t n_tiles, uint32_t* tile_bin, uint32_t* group_counts) {
     extern __shared__ uint32_t lds_stack[];
     uint32_t* stack = lds_stack + threadIdx.x;
     // one wave = 4 tiles x 16 pixels (a staggered 4x4 subsample of each 8x8 tile)
@@ -1383,36 +1426,55 @@ classify_kernel(const DevSceneView S, const RenderParams P, uint32_t n_tiles, ui
     // Round shape of the tile (render_kernel): where the rays of a pixel spread over more than P.lens_coc_px pixels,
     // rounds of one sample index (one lens cell) of 8 neighbouring pixels are more coherent than rounds of one pixel.
     const uint32_t by_lens = (hits > 0.0f && coc > P.lens_coc_px * hits) ? 0x100u : 0u;
-    if (live && k == 0u) tile_bin[tile] = cls | by_lens;
+    if (live && k == 0u) {
+        tile_bin[tile] = cls | by_lens;
+        atomicAdd(group_counts + (tile / RT_ORDER_GROUP) * RT_COST_BINS + cls, 1u);      // (at most RT_ORDER_GROUP adds per address)
+    }
 }
 
-// Stable counting sort of the tiles by class (row-major order kept inside a class, so that waves
-// running at the same time stay on neighbouring tiles).  One block; thread t owns a contiguous run.
-__global__ void __launch_bounds__(1024)
-order_kernel(const uint32_t* tile_bin, uint32_t n_tiles, uint32_t* tile_order) {
-    __shared__ uint32_t counts[1024][RT_COST_BINS];
-    __shared__ uint32_t class_base[RT_COST_BINS];
-    const uint32_t t = threadIdx.x, per = (n_tiles + 1023u) / 1024u;
-    const uint32_t lo = t * per < n_tiles ? t * per : n_tiles, hi = lo + per < n_tiles ? lo + per : n_tiles;
-    uint32_t mine[RT_COST_BINS] = {0u, 0u, 0u, 0u};
-    for (uint32_t i = lo; i < hi; i++) mine[tile_bin[i] & 0xffu]++;
-    for (uint32_t b = 0; b < RT_COST_BINS; b++) counts[t][b] = mine[b];
-    __syncthreads();
-    if (t < RT_COST_BINS) {                            // exclusive scan over the threads, per class
-        uint32_t run = 0;
-        for (uint32_t k = 0; k < 1024u; k++) { const uint32_t c = counts[k][t]; counts[k][t] = run; run += c; }
-        class_base[t] = run;                           // total of the class for now
+// Stable counting sort of the tiles by class (row-major order kept inside a class, so that waves running at the same time stay on
+// neighbouring tiles), in parallel: block g owns the tiles [g, g + 1) x RT_ORDER_GROUP.  classify_kernel has counted every group's tiles per
+// class (group_counts, zeroed per call), so a block finds where its tiles of each class start from the counts of the groups before it, and a
+// tile's place among its block's from a ballot per wave and the counts of the waves before it.  (Round 2's version was one block whose scan
+// over 1024 partial counts ran on four threads: 65 us per launch whatever the share of the frame - a fixed cost that an 8-rank split of a
+// 10 ms frame pays in full.  This one: a few us.)
+__global__ void __launch_bounds__(RT_ORDER_GROUP)
+order_kernel(const uint32_t* tile_bin, uint32_t n_tiles, const uint32_t* group_counts, uint32_t* tile_order) {
+    __shared__ uint32_t wave_count[RT_ORDER_GROUP / 64u][RT_COST_BINS];
+    __shared__ uint32_t group_base[RT_COST_BINS];
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6, g = blockIdx.x, n_groups = gridDim.x;
+    const uint32_t i = g * RT_ORDER_GROUP + t;
+    const bool live = i < n_tiles;
+    const uint32_t bin = live ? tile_bin[i] : 0u, cls = bin & 0xffu;
+    // where this block's tiles of each class start: the class's base (all tiles of the classes before it) + the groups before this one
+    if (wave == 0u) {
+        uint32_t total[RT_COST_BINS], before[RT_COST_BINS];
+#pragma unroll
+        for (uint32_t b = 0; b < RT_COST_BINS; b++) {
+            uint32_t a = 0, c = 0;
+            for (uint32_t k = lane; k < n_groups; k += 64u) { const uint32_t v = group_counts[k * RT_COST_BINS + b]; a += v; c += k < g ? v : 0u; }
+            for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off, 64); c += __shfl_xor(c, off, 64); }
+            total[b] = a; before[b] = c;
+        }
+        if (lane == 0u) {
+            uint32_t run = 0;
+#pragma unroll
+            for (uint32_t b = 0; b < RT_COST_BINS; b++) { group_base[b] = run + before[b]; run += total[b]; }
+            if (g == 0u) tile_order[-1] = total[0] + total[1] + total[2];      // every tile that hits something: all classes but "sky only"
+        }
+    }
+    uint32_t rank = 0;
+#pragma unroll
+    for (uint32_t b = 0; b < RT_COST_BINS; b++) {
+        const unsigned long long m = __ballot(live && cls == b);
+        if (cls == b) rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_count[wave][b] = (uint32_t)__popcll(m);
     }
     __syncthreads();
-    if (t == 0) {
-        tile_order[-1] = class_base[0] + class_base[1] + class_base[2];      // every tile that hits something
-        uint32_t run = 0;
-        for (uint32_t b = 0; b < RT_COST_BINS; b++) { const uint32_t c = class_base[b]; class_base[b] = run; run += c; }
-    }
-    __syncthreads();
-    uint32_t pos[RT_COST_BINS];
-    for (uint32_t b = 0; b < RT_COST_BINS; b++) pos[b] = class_base[b] + counts[t][b];
-    for (uint32_t i = lo; i < hi; i++) { const uint32_t b = tile_bin[i]; tile_order[pos[b & 0xffu]++] = i | ((b >> 8) << 31); }      // bit 31: rounds by lens cell
+    if (!live) return;
+    uint32_t pos = group_base[cls] + rank;
+    for (uint32_t w = 0; w < wave; w++) pos += wave_count[w][cls];
+    tile_order[pos] = i | ((bin >> 8) << 31);      // bit 31: rounds by lens cell
 }
 
 __global__ void __launch_bounds__(RT_BLOCK)
@@ -1464,19 +1526,27 @@ primary_wide_kernel(const DevSceneView S, const RenderParams P, const Word4* wid
 // (scene_build.cpp: rotate() = types.rs:200 with cos / sin evaluated by the host libm and handed over in the transform
 // records), so the boxes are bit for bit those a fresh rt_scene_create would compute.  Also refreshes the entity's inline
 // first translation.  ent_box: 8 floats per TLAS position (lo.xyz, -, hi.xyz, -).
-__global__ void refit_entities_kernel(DevEntity* entities, const Word4* xforms, const DevMesh* meshes, float* ent_box, uint32_t n) {
+// ent_out may be another array than ent_in (rt_scene_rebuild_tlas stages the moved records before it commits): the whole record is then copied.
+__global__ void refit_entities_kernel(const DevEntity* ent_in, DevEntity* ent_out, const Word4* xforms, const DevMesh* meshes, float* ent_box, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    Word4* ew = entities[i].w;
-    const Word4 e0 = ldw(ew), e1 = ldw(ew + 1);
+    Word4* ew = ent_out[i].w;
+    const Word4 e0 = ldw(ent_in[i].w), e1 = ldw(ent_in[i].w + 1);
+    if (ent_in != ent_out) {
+        const Word4 e2 = ldw(ent_in[i].w + 2);
+        *reinterpret_cast<float4*>(ew) = *reinterpret_cast<const float4*>(&e0); *reinterpret_cast<float4*>(ew + 1) = *reinterpret_cast<const float4*>(&e1);
+        *reinterpret_cast<float4*>(ew + 2) = *reinterpret_cast<const float4*>(&e2);
+    }
     const uint32_t kind = e1.u[0] & 0xff, n_trans = (e1.u[0] >> 8) & 0xff, n_rot = (e1.u[0] >> 16) & 0xff;
     const Word4* x = xforms + e1.u[2];
     const float inf = __builtin_inff();
     F3 lo, hi;
-    bool infinite = false;
     if (kind == RT_HITABLE_SPHERE) { const float r = e0.f[3]; lo = f3(0.0f - r, 0.0f - r, 0.0f - r); hi = f3(0.0f + r, 0.0f + r, 0.0f + r); }      // sphere.rs:55-58
-    else if (kind == RT_HITABLE_PLANE) { lo = f3(-inf, -inf, -inf); hi = f3(inf, inf, inf); infinite = true; }                                  // plane.rs:92-95
+    else if (kind == RT_HITABLE_PLANE) { lo = f3(-inf, -inf, -inf); hi = f3(inf, inf, inf); }                                                   // plane.rs:92-95
     else { const Word4* mw = meshes[e1.u[1]].w; const Word4 m1 = ldw(mw + 1), m2 = ldw(mw + 2); lo = f3(m1.f[0], m1.f[1], m1.f[2]); hi = f3(m1.f[3], m2.f[0], m2.f[1]); }
+    // implementation.rs:264 (`!aabb.is_infinite()`): rotations are skipped for ANY hitable whose box is infinite on all six sides - a plane, but also a
+    // sphere of infinite radius or a mesh with infinite bounds (scene_build.cpp: box_is_infinite) - not by the kind of hitable
+    const bool infinite = lo.x == -inf && lo.y == -inf && lo.z == -inf && hi.x == inf && hi.y == inf && hi.z == inf;
     // AABB::corners, implementation.rs:120-131
     F3 c[8] = {lo, f3(lo.x, lo.y, hi.z), f3(lo.x, hi.y, lo.z), f3(hi.x, lo.y, lo.z), hi, f3(hi.x, hi.y, lo.z), f3(hi.x, lo.y, hi.z), f3(lo.x, hi.y, hi.z)};
     if (!infinite)
@@ -1621,6 +1691,35 @@ struct Workspace {
     }
 };
 
+// rt_render_frame_multi: per-replica streams, events and buffers (owned by the scene passed first)
+struct MultiContext {
+    std::vector<RtScene*> scenes;
+    struct PerDevice {
+        int device = 0;
+        hipStream_t stream = nullptr;
+        hipEvent_t done = nullptr;
+        bool direct = false;                  // this device can write GPU 0's memory (the same device, or peer access enabled)
+        DeviceBuffer counters, packed_rgb, packed_rgba, accum;
+        DeviceBuffer staging;                 // on GPU 0: this device's accumulator, copied over (spp mode)
+        RtRayCounters host_counters{};
+        int rc = RT_OK; std::string error;
+    };
+    std::vector<PerDevice> dev;
+    DeviceBuffer total;                       // on GPU 0 (spp mode)
+    hipStream_t stream0 = nullptr;
+    void release() {
+        for (auto& d : dev) {
+            (void)hipSetDevice(d.device);
+            if (d.stream) { (void)hipStreamSynchronize(d.stream); (void)hipStreamDestroy(d.stream); }
+            if (d.done) (void)hipEventDestroy(d.done);
+            d.counters.release(); d.packed_rgb.release(); d.packed_rgba.release(); d.accum.release();
+        }
+        if (!dev.empty()) { (void)hipSetDevice(dev[0].device); for (auto& d : dev) d.staging.release(); total.release(); }
+        dev.clear(); scenes.clear();
+    }
+};
+
+
 #define RT_MAX_WORKSPACES 8
 
 // Switches of the schedule and the sampler (rt_scene_set_option).  Their defaults can be preset through the
@@ -1631,6 +1730,7 @@ struct SceneOptions {
     int round_units = 8;            // RT_OPT_ROUND_UNITS
     float lens_coc_px = 4.0f;       // RT_OPT_LENS_COC_PX (4 px measured best; 3..8 within 1 %)
     uint32_t debug_stack_entries = 0;   // RT_OPT_DEBUG_STACK_ENTRIES: 0 = what the trees need
+    uint32_t debug_rebuild_stack_limit = 0;   // RT_OPT_DEBUG_REBUILD_STACK_LIMIT: rt_scene_rebuild_tlas refuses trees that need more stack entries (0 = the LDS limit)
 };
 
 struct RtScene {
@@ -1639,6 +1739,14 @@ struct RtScene {
     SceneOptions opt;               // every call works on a snapshot taken under opt_lock
     uint32_t* dev_error_host = nullptr;   // host-mapped word the kernels set on a capacity overflow (RT_DEVERR_*): readable without a sync
     uint32_t* dev_error_dev = nullptr;
+    // the same host-mapped allocation, 64 bytes apart: [16] the cancel word (rt_scene_cancel; read by the render kernel at its block claims),
+    // [32] the progress word (written by the render kernel); the totals live on the host
+    volatile uint32_t* cancel_host() const { return dev_error_host + 16; }
+    volatile uint32_t* progress_host() const { return dev_error_host + 32; }
+    std::atomic<uint64_t> progress_total{0};        // blocks of the call in flight (all its launches)
+    struct MultiContext* multi = nullptr;           // rt_render_frame_multi: streams, events and buffers, owned by the scene passed first
+    std::mutex multi_frame_lock;
+    DeviceBuffer multi_frame_rgb, multi_frame_rgba; // rt_render_frame_multi_host: the frame on this device before it is copied to the host
     DevSceneView view{};
     RtSceneInfo info{};
     std::vector<uint32_t> tlas_order;
@@ -1666,8 +1774,12 @@ struct RtScene {
         LbvhNode* lnodes = nullptr;
         uint32_t *parent = nullptr, *height = nullptr, *arrived = nullptr, *number = nullptr, *queue = nullptr;
         float *box = nullptr, *bounds = nullptr;
-        DevEntity* entities_alt = nullptr;
+        DevEntity* entities_alt = nullptr;      // the build's OUTPUT (key order); swapped with the scene's arrays when a build commits
         float* ent_box_alt = nullptr;
+        DevEntity* entities_stage = nullptr;    // moved entity records / boxes / transform records before the permutation: a build that is refused
+        float* ent_box_stage = nullptr;         // (RT_E_DEPTH) has written nothing a render call reads
+        Word4* xforms_stage = nullptr;
+        bool topology_stale = false;            // a refused build left ANOTHER topology in lnodes / number than the scene's records: no refit from them
     } rebuild;
     // Device-pointer entry points run on the CALLER's stream and share this workspace:
     // `lock` serialises their enqueueing, the caller keeps them on one stream.
@@ -1736,6 +1848,7 @@ int upload(RtScene* s, const std::vector<T>& v, const T** dst) {
 int check_device_error(const RtScene* scene) {
     const uint32_t e = scene->dev_error_host ? *(volatile const uint32_t*)scene->dev_error_host : 0u;
     if (e == 0u) return RT_OK;
+    if (e & RT_DEVERR_POISONED) return set_error(RT_E_HIP, "an earlier rt_scene_rebuild_tlas / rt_scene_update_transforms failed half way: the scene's device data is inconsistent; create the scene anew");
     return set_error(RT_E_DEPTH, (e & RT_DEVERR_STACK) ? "a render kernel ran out of traversal stack (BVH deeper than the scene build accounted for): pixels of that launch are incomplete"
                                                        : "a render kernel ran out of deferred-ray slots: pixels of that launch are incomplete");
 }
@@ -1744,6 +1857,7 @@ int validate_call(const RtScene* scene, const RtSettings* st, const RtRenderChun
     if (!scene || !st || !ch) return set_error(RT_E_INVALID, "null argument");
     if (scene->device == RT_DEVICE_HOST_ONLY) return set_error(RT_E_NO_DEVICE, "scene was created host-only (RT_DEVICE_HOST_ONLY): nothing to render on");
     if (int rc = check_device_error(scene)) return rc;      // sticky: an earlier launch on this scene overflowed a capacity
+    if (scene->dev_error_host && *scene->cancel_host() != 0u) return set_error(RT_E_CANCELLED, "the scene is cancelled (rt_scene_cancel): clear it with rt_scene_cancel(scene, 0)");
     if (st->width == 0 || st->height == 0 || st->samples_per_pixel == 0) return set_error(RT_E_INVALID, "RenderSettings: width, height and samples_per_pixel must be > 0");
     if (st->width > 65535 || st->height > 65535) return set_error(RT_E_LIMIT, "RenderSettings: image sides are limited to 65535 (RNG counter packs x | y<<16)");
     if (st->max_reflections > RT_MAX_REFLECTIONS) return set_error(RT_E_LIMIT, "RenderSettings: max_reflections is limited to 31 (recursion-tree node id is 32 bit)");
@@ -1754,6 +1868,9 @@ int validate_call(const RtScene* scene, const RtSettings* st, const RtRenderChun
         return set_error(RT_E_LIMIT, "RenderChunk: more than 2^28 pixels in one call; render the image in several chunks (create_render_chunks)");
     return RT_OK;
 }
+
+// bytes of the tile-order scratch of a launch over n_tiles tiles (enqueue_accumulate)
+size_t order_buffer_bytes(size_t n_tiles) { return ((n_tiles + RT_ORDER_GROUP - 1) / RT_ORDER_GROUP) * RT_COST_BINS * 4 + n_tiles * 8 + 16; }
 
 // Enqueue: accumulate the sum of clamped samples [first, first+count) of the chunk
 // into `acc` (float3 image with pitch acc_pitch, chunk origin at acc_x/acc_y).
@@ -1807,18 +1924,34 @@ int enqueue_accumulate(RtScene* scene, Workspace& ws, const RtSettings* st, cons
     P.lens_coc_px = opt.lens_coc_px;      // circle of confusion in pixels from which a tile runs lens-cell rounds (a huge value turns them off)
     P.lens_stratify = opt.lens_stratify ? 1u : 0u;
     P.error_flag = scene->dev_error_dev;
+    P.cancel_word = scene->dev_error_dev + 16; P.progress_word = scene->dev_error_dev + 32; P.progress_base = 0;
+    {
+        // progress of this call: blocks over all its launches (an estimate for concurrent calls on one scene: they share the words)
+        uint64_t blocks_total = 0;
+        for (uint32_t b0 = 0; b0 < nseg; b0 += batch) {
+            const uint32_t bn = (nseg - b0 < batch) ? nseg - b0 : batch;
+            const uint32_t s_lo = (seg_lo + b0) * RT_SAMPLE_SEGMENT > sample_first ? (seg_lo + b0) * RT_SAMPLE_SEGMENT : sample_first;
+            const uint32_t s_hi = (seg_lo + b0 + bn) * RT_SAMPLE_SEGMENT < sample_first + sample_count ? (seg_lo + b0 + bn) * RT_SAMPLE_SEGMENT : sample_first + sample_count;
+            blocks_total += (uint64_t)(pix_slots / 64) * ((s_hi - 1) / unit_len - s_lo / unit_len + 1);
+        }
+        *scene->progress_host() = 0u;
+        scene->progress_total.store(blocks_total);
+    }
     DevSceneView view = scene->view;
     if (opt.debug_stack_entries && opt.debug_stack_entries < view.stack_entries) view.stack_entries = opt.debug_stack_entries;      // (tests of RT_E_DEPTH)
     // expensive tiles first (whole-segment launches over enough tiles to have a tail worth hiding)
     const uint32_t n_tiles = pix_slots / 64;
     static const bool order_tiles = []() { const char* e = getenv("RT_TILE_ORDER"); return !e || atoi(e) != 0; }();
     if (!fine && order_tiles && n_tiles >= 256) {
-        if ((rc = ws.order.ensure((size_t)n_tiles * 8 + 16))) return rc;
-        uint32_t* tile_bin = (uint32_t*)ws.order.p; uint32_t* tile_order = tile_bin + n_tiles + 4;      // [-1] = expensive-tile count
+        const uint32_t n_groups = (n_tiles + RT_ORDER_GROUP - 1u) / RT_ORDER_GROUP;
+        if ((rc = ws.order.ensure(order_buffer_bytes(n_tiles)))) return rc;
+        // layout: [group_counts: n_groups x 4][tile_bin: n_tiles][3 spare + the expensive-tile count = tile_order[-1]][tile_order: n_tiles]
+        uint32_t* group_counts = (uint32_t*)ws.order.p; uint32_t* tile_bin = group_counts + (size_t)n_groups * RT_COST_BINS; uint32_t* tile_order = tile_bin + n_tiles + 4;
+        HIP_TRY(hipMemsetAsync(group_counts, 0, (size_t)n_groups * RT_COST_BINS * 4, stream));
         hipLaunchKernelGGL(classify_kernel, dim3((n_tiles * 16 + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), scene->stack_lds_bytes, stream, view, P,
-                           n_tiles, tile_bin);
+                           n_tiles, tile_bin, group_counts);
         HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t*)tile_bin, n_tiles, tile_order);
+        hipLaunchKernelGGL(order_kernel, dim3(n_groups), dim3(RT_ORDER_GROUP), 0, stream, (const uint32_t*)tile_bin, n_tiles, (const uint32_t*)group_counts, tile_order);
         HIP_TRY(hipGetLastError());
         P.tile_order = tile_order;
     }
@@ -1851,8 +1984,8 @@ int enqueue_accumulate(RtScene* scene, Workspace& ws, const RtSettings* st, cons
 #ifdef RT_PHASE_STATS
         if (ws.no_alloc) return set_error(RT_E_INVALID, "the phase-statistics build allocates: not with the no-alloc entry point");
         static unsigned long long* phase_dev = nullptr;
-        if (!phase_dev) HIP_TRY(hipMalloc((void**)&phase_dev, PH_COUNT * 16));
-        HIP_TRY(hipMemsetAsync(phase_dev, 0, PH_COUNT * 16, stream));
+        if (!phase_dev) HIP_TRY(hipMalloc((void**)&phase_dev, PH_COUNT * 16 + 8 * 32));
+        HIP_TRY(hipMemsetAsync(phase_dev, 0, PH_COUNT * 16 + 8 * 32, stream));
         P.phase_stats = phase_dev;
 #endif
         {
@@ -1888,7 +2021,7 @@ int enqueue_accumulate(RtScene* scene, Workspace& ws, const RtSettings* st, cons
         HIP_TRY(hipGetLastError());
 #ifdef RT_PHASE_STATS
         {
-            unsigned long long h[PH_COUNT * 2];
+            unsigned long long h[PH_COUNT * 2 + 32];
             HIP_TRY(hipMemcpyAsync(h, phase_dev, sizeof(h), hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));
 #ifdef RT_PHASE_TIME
@@ -1901,6 +2034,11 @@ int enqueue_accumulate(RtScene* scene, Workspace& ws, const RtSettings* st, cons
             static const char* names[PH_COUNT] = {"node", "tri", "entity", "shade", "shade_path_hit", "shade_shadow_hit", "stage_a", "stage_c", "trace_init", "burst", "leaf_tri", "leaf_tlas", "outer", "pop_inst"};
             for (int k = 0; k < PH_COUNT; k++)
                 fprintf(stderr, "phase %-18s lanes %14llu passes %12llu util %.3f\n", names[k], h[2 * k], h[2 * k + 1], h[2 * k + 1] ? (double)h[2 * k] / (64.0 * (double)h[2 * k + 1]) : 0.0);
+            for (int k = 1; k < 8; k++) {      // bursts by the kinds of ray they hold: c camera, s secondary, h shadow
+                const unsigned long long* b = h + 2 * PH_COUNT + 4 * k;
+                if (b[0]) fprintf(stderr, "bursts %c%c%c  n %11llu  start lanes %5.1f  iterations %7.1f  (share of all iterations below)  lanes tracing per iteration %5.1f  total iterations %13llu\n",
+                                  (k & 1) ? 'c' : '-', (k & 2) ? 's' : '-', (k & 4) ? 'h' : '-', b[0], (double)b[1] / (double)b[0], (double)b[2] / (double)b[0], (double)b[3] / (double)b[2], b[2]);
+            }
 #endif
         }
 #endif
@@ -1912,6 +2050,7 @@ int enqueue_accumulate(RtScene* scene, Workspace& ws, const RtSettings* st, cons
         hipLaunchKernelGGL(fold_kernel, dim3((npix + 255) / 256), dim3(256), 0, stream, (const float*)ws.partial.p, P.unit_count, P.unit_first, unit_len, npix, acc, acc_pitch,
                            ch->width, acc_x, acc_y, (init_zero && b0 == 0) ? 1 : 0, tiles_x, pix_slots);
         HIP_TRY(hipGetLastError());
+        P.progress_base += (uint32_t)((uint64_t)(pix_slots / 64) * P.unit_count);
     }
     return RT_OK;
 }
@@ -1981,8 +2120,8 @@ RtScene* rt_scene_create(const RtSceneDesc* desc, int device) {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_kernel<true, true, true, true, true, true, true>, RT_BLOCK, s->lds_bytes) != hipSuccess || per_cu < 1) per_cu = 1;
     s->grid_blocks = prop.multiProcessorCount * per_cu;
     if (s->shared.init(false)) return fail();
-    if (hipHostMalloc((void**)&s->dev_error_host, 64, hipHostMallocMapped) != hipSuccess) { s->dev_error_host = nullptr; set_error(RT_E_HIP, "hipHostMalloc (error word) failed"); return fail(); }
-    *s->dev_error_host = 0u;
+    if (hipHostMalloc((void**)&s->dev_error_host, 256, hipHostMallocMapped) != hipSuccess) { s->dev_error_host = nullptr; set_error(RT_E_HIP, "hipHostMalloc (error word) failed"); return fail(); }
+    memset(s->dev_error_host, 0, 256);      // error word, cancel word, progress word: one cache line each
     if (hipHostGetDevicePointer((void**)&s->dev_error_dev, s->dev_error_host, 0) != hipSuccess) { set_error(RT_E_HIP, "hipHostGetDevicePointer failed"); return fail(); }
     // defaults of the options from the environment, read once
     if (const char* e = getenv("RT_LENS_STRATIFY")) s->opt.lens_stratify = atoi(e) != 0;
@@ -2016,6 +2155,9 @@ int rt_scene_set_option(RtScene* scene, uint32_t option, double value) {
                 *scene->dev_error_host = 0u;
             }
             return RT_OK;
+        case RT_OPT_DEBUG_REBUILD_STACK_LIMIT:
+            if (!(value >= 0.0 && value <= 1024.0)) return set_error(RT_E_INVALID, "RT_OPT_DEBUG_REBUILD_STACK_LIMIT: 0 (the LDS limit) .. 1024");
+            scene->opt.debug_rebuild_stack_limit = (uint32_t)value; return RT_OK;
         default: return set_error(RT_E_INVALID, "rt_scene_set_option: unknown option");
     }
 }
@@ -2025,6 +2167,8 @@ void rt_scene_destroy(RtScene* s) {
     if (s->device == RT_DEVICE_HOST_ONLY) { delete s; return; }
     (void)hipSetDevice(s->device);
     (void)hipDeviceSynchronize();
+    if (s->multi) { s->multi->release(); delete s->multi; s->multi = nullptr; (void)hipSetDevice(s->device); }
+    s->multi_frame_rgb.release(); s->multi_frame_rgba.release();
     for (auto& w : s->pool) w->release();
     s->shared.release();
     for (void* p : s->allocations) (void)hipFree(p);
@@ -2080,7 +2224,7 @@ int rt_render_chunk_device_noalloc(RtScene* scene, const RtSettings* st, const R
     Workspace ws; ws.no_alloc = true;
     auto carve = [&](DeviceBuffer& b, size_t n) { b.p = base + at; b.bytes = n; b.fixed = true; at += up(n); };
     carve(ws.ctrl, 1024 + RT_QUEUES * 64);
-    carve(ws.order, (size_t)(pix_slots / 64) * 8 + 16);
+    carve(ws.order, order_buffer_bytes((size_t)(pix_slots / 64)));
     carve(ws.accum, (size_t)ch->width * ch->height * 12);
     carve(ws.partial, RT_NOALLOC_SCRATCH_BYTES - at);           // the rest: as many units per launch as fit
     std::lock_guard<std::mutex> g(g_scratch_call_lock[scene->device]);
@@ -2106,6 +2250,7 @@ int rt_render_chunk(RtScene* scene, const RtSettings* st, const RtRenderChunk* c
     HIP_TRY_SYNC(hipMemcpyAsync(&c, ws.ctrl.p, sizeof(c), hipMemcpyDeviceToHost, ws.stream), ws.stream);      // (`c` is a local: never return with this in flight)
     HIP_TRY(hipStreamSynchronize(ws.stream));
     if ((rc = check_device_error(scene))) return rc;
+    if (*scene->cancel_host() != 0u) return set_error(RT_E_CANCELLED, "rt_render_chunk: cancelled (rt_scene_cancel); the output buffers hold unfinished pixels");
     if (counters) { counters->primary += c.primary; counters->secondary += c.secondary; counters->shadow += c.shadow; counters->samples += c.samples; }
     return RT_OK;
 }
@@ -2129,13 +2274,18 @@ int rt_scene_update_transforms(RtScene* scene, const RtV3* translations, uint64_
     // from a fresh rt_scene_create in 1-57 pixels).  Nothing on the device has been touched yet.
     if (loose) return set_error(RT_E_INVALID, "rt_scene_update_transforms: a rotation axis is not of unit length - entity boxes do not bound their hits and only the tree "
                                               "the reference builds for these transforms reproduces them; use rt_scene_create");
+    if (!scene->refit_valid && scene->rebuild.topology_stale)
+        return set_error(RT_E_INVALID, "rt_scene_update_transforms: the last rt_scene_rebuild_tlas on this scene was refused (RT_E_DEPTH) and left its working buffers describing "
+                                       "another tree than the scene's; call rt_scene_rebuild_tlas again (or create the scene anew)");
     Word4* xforms_dev = const_cast<Word4*>(scene->view.xforms);
     DevNode* nodes_dev = const_cast<DevNode*>(scene->view.nodes);
     DevEntity* entities_dev = const_cast<DevEntity*>(scene->view.entities);
     HIP_TRY(hipMemcpyAsync(xforms_dev, scene->xforms_host.data(), scene->xforms_host.size() * sizeof(Word4), hipMemcpyHostToDevice, sm));
     // device: entity boxes, then the tree bottom-up (one launch per level, deepest first), then the root box
     const uint32_t n = scene->view.entity_count;
-    hipLaunchKernelGGL(refit_entities_kernel, dim3((n + 255) / 256), dim3(256), 0, sm, entities_dev, (const Word4*)xforms_dev, scene->view.meshes, scene->ent_box_dev, n);
+    if (n == 0) { HIP_TRY(hipStreamSynchronize(sm)); return RT_OK; }      // an empty scene keeps the empty root box of rt_scene_create
+    hipLaunchKernelGGL(refit_entities_kernel, dim3((n + 255) / 256), dim3(256), 0, sm, (const DevEntity*)entities_dev, entities_dev, (const Word4*)xforms_dev, scene->view.meshes,
+                       scene->ent_box_dev, n);
     HIP_TRY_SYNC(hipGetLastError(), sm);
     if (scene->refit_valid) {
         for (size_t l = 0; l + 1 < scene->refit_level_start.size(); l++) {
@@ -2148,6 +2298,7 @@ int rt_scene_update_transforms(RtScene* scene, const RtV3* translations, uint64_
         // the tree was built on the device (rt_scene_rebuild_tlas): its topology and record numbers are still in the build's buffers, so a refit
         // is the build without the sort: boxes bottom-up, records rewritten
         RtScene::TlasRebuild& rb = scene->rebuild;
+        // (checked BEFORE anything was enqueued, below: moved up)
         const dim3 blk(256), per_entity((n + 255) / 256), per_inner((n - 1 + 255) / 256);
         HIP_TRY_SYNC(hipMemsetAsync(rb.arrived, 0, (size_t)(n - 1) * 4, sm), sm);
         hipLaunchKernelGGL(lbvh_boxes_kernel, per_entity, blk, 0, sm, (const LbvhNode*)rb.lnodes, (const uint32_t*)rb.parent, n, (const float*)scene->ent_box_dev, rb.box,
@@ -2180,22 +2331,26 @@ int rt_scene_rebuild_tlas(RtScene* scene, const RtV3* translations, uint64_t tra
     HIP_TRY(hipSetDevice(scene->device));
     hipStream_t sm = (hipStream_t)stream;
     const uint32_t n = scene->view.entity_count;
+    if (n == 0) return RT_OK;                 // an empty scene keeps the empty root box and the never-followed root ref of rt_scene_create
     RtScene::TlasRebuild& rb = scene->rebuild;
+    const size_t m = n > 1 ? n - 1 : 1;
+    if (scene->node_count + m >= ((size_t)1 << 26))
+        return set_error(RT_E_LIMIT, "rt_scene_rebuild_tlas: the rebuilt tree's records would not fit the 2^26 records the walk can address");
     if (!rb.ready) {
-        // first call: the build's buffers (about 150 bytes per entity) and a node array with room for n - 1 more records
+        // first call: the build's buffers (about 250 bytes per entity) and a node array with room for n - 1 more records
         auto dev_alloc = [&](void** p, size_t bytes) -> int {
             HIP_TRY(hipMalloc(p, bytes ? bytes : 16));
             scene->allocations.push_back(*p);
             return RT_OK;
         };
-        const size_t m = n > 1 ? n - 1 : 1;
         int rc;
         if ((rc = dev_alloc((void**)&rb.keys_a, (size_t)(n + 1) * 8)) || (rc = dev_alloc((void**)&rb.keys_b, (size_t)(n + 1) * 8)) ||
             (rc = dev_alloc((void**)&rb.lnodes, m * sizeof(LbvhNode))) || (rc = dev_alloc((void**)&rb.parent, (size_t)(2 * (size_t)n + 1) * 4)) ||
             (rc = dev_alloc((void**)&rb.height, m * 4)) || (rc = dev_alloc((void**)&rb.arrived, m * 4)) || (rc = dev_alloc((void**)&rb.number, m * 4)) ||
             (rc = dev_alloc((void**)&rb.queue, ((size_t)scene->tlas_hot_records + 1) * 4)) || (rc = dev_alloc((void**)&rb.box, m * 32)) ||
             (rc = dev_alloc((void**)&rb.bounds, 64)) || (rc = dev_alloc((void**)&rb.entities_alt, (size_t)(n + 1) * sizeof(DevEntity))) ||
-            (rc = dev_alloc((void**)&rb.ent_box_alt, ((size_t)n + 1) * 32)))
+            (rc = dev_alloc((void**)&rb.ent_box_alt, ((size_t)n + 1) * 32)) || (rc = dev_alloc((void**)&rb.entities_stage, (size_t)(n + 1) * sizeof(DevEntity))) ||
+            (rc = dev_alloc((void**)&rb.ent_box_stage, ((size_t)n + 1) * 32)) || (rc = dev_alloc((void**)&rb.xforms_stage, (scene->xforms_words + 1) * sizeof(Word4))))
             return rc;
         rb.sort_temp_bytes = 0;
         HIP_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, rb.sort_temp_bytes, rb.keys_a, rb.keys_b, (int)n, 0, 62, sm));
@@ -2204,7 +2359,7 @@ int rt_scene_rebuild_tlas(RtScene* scene, const RtV3* translations, uint64_t tra
         if ((rc = dev_alloc((void**)&bigger, (scene->node_count + m) * sizeof(DevNode)))) return rc;
         HIP_TRY(hipMemcpyAsync(bigger, scene->view.nodes, scene->node_count * sizeof(DevNode), hipMemcpyDeviceToDevice, sm));
         HIP_TRY(hipStreamSynchronize(sm));
-        scene->view.nodes = bigger;           // (the old array stays allocated until the scene is destroyed: launches in flight may still read it)
+        scene->view.nodes = bigger;           // (same contents; the old array stays allocated until the scene is destroyed: launches in flight may still read it)
         rb.ready = true;
     }
     // host: transform records, as in rt_scene_update_transforms
@@ -2216,68 +2371,88 @@ int rt_scene_rebuild_tlas(RtScene* scene, const RtV3* translations, uint64_t tra
     // (measured: 62 of 323 such random scenes differ).  Nothing on the device has been touched yet.
     if (loose) return set_error(RT_E_INVALID, "rt_scene_rebuild_tlas: a rotation axis is not of unit length - entity boxes do not bound their hits, only the reference's own tree "
                                               "reproduces them; use rt_scene_update_transforms (refit) or rt_scene_create");
-    Word4* xforms_dev = const_cast<Word4*>(scene->view.xforms);
+    // ---- phase 1: everything up to the height of the new tree goes into the build's OWN buffers.  The scene a render call sees (transform records,
+    // entity records and boxes, node records, view.*) is untouched until the new tree is known to fit the traversal stack, so a refusal leaves the
+    // scene exactly as it was.
     DevNode* nodes_dev = const_cast<DevNode*>(scene->view.nodes);
-    DevEntity* ent_cur = const_cast<DevEntity*>(scene->view.entities);
-    float* box_cur = scene->ent_box_dev;
-    HIP_TRY(hipMemcpyAsync(xforms_dev, scene->xforms_host.data(), scene->xforms_host.size() * sizeof(Word4), hipMemcpyHostToDevice, sm));
-    scene->refit_valid = false;               // from here on the old tree no longer matches the entity boxes
-    uint32_t root_ref = RT_REF_LEAF_BIT;      // (n == 0: never followed, the root box is empty)
+    const DevEntity* ent_live = scene->view.entities;
+    DevEntity* ent_new = rb.entities_alt; float* box_new = rb.ent_box_alt;      // key order: what the scene will use
     const uint32_t hot = scene->tlas_hot_records, append_base = (uint32_t)scene->node_count;
+    const dim3 blk(256), per_entity((n + 255) / 256), per_inner((n > 1 ? n - 1 + 255 : 255) / 256);
     uint32_t height0 = 0;
-    if (n > 0) {
-        const dim3 blk(256), per_entity((n + 255) / 256);
-        hipLaunchKernelGGL(refit_entities_kernel, per_entity, blk, 0, sm, ent_cur, (const Word4*)xforms_dev, scene->view.meshes, box_cur, n);
-        hipLaunchKernelGGL(lbvh_bounds_kernel, dim3(1), blk, 0, sm, (const float*)box_cur, n, rb.bounds);
-        hipLaunchKernelGGL(lbvh_keys_kernel, per_entity, blk, 0, sm, (const float*)box_cur, n, (const float*)rb.bounds, rb.keys_a);
-        HIP_TRY_SYNC(hipGetLastError(), sm);
-        size_t temp_bytes = rb.sort_temp_bytes;
-        HIP_TRY_SYNC(hipcub::DeviceRadixSort::SortKeys(rb.sort_temp, temp_bytes, rb.keys_a, rb.keys_b, (int)n, 0, 62, sm), sm);
-        hipLaunchKernelGGL(lbvh_permute_kernel, per_entity, blk, 0, sm, (const unsigned long long*)rb.keys_b, n, (const DevEntity*)ent_cur, rb.entities_alt,
-                           (const float*)box_cur, rb.ent_box_alt, (uint32_t*)nullptr);
-        std::swap(ent_cur, rb.entities_alt); std::swap(box_cur, rb.ent_box_alt);
-        root_ref = RT_REF_LEAF_BIT | ((n - 1u) << RT_REF_COUNT_SHIFT);      // all entities in one leaf ...
-        if (n > RT_LBVH_LEAF) {                                               // ... or a tree
-            const dim3 per_inner((n - 1 + 255) / 256);
-            HIP_TRY_SYNC(hipMemsetAsync(rb.arrived, 0, (size_t)(n - 1) * 4, sm), sm);
-            hipLaunchKernelGGL(lbvh_topology_kernel, per_inner, blk, 0, sm, (const unsigned long long*)rb.keys_b, n, rb.lnodes, rb.parent);
-            hipLaunchKernelGGL(lbvh_boxes_kernel, per_entity, blk, 0, sm, (const LbvhNode*)rb.lnodes, (const uint32_t*)rb.parent, n, (const float*)box_cur, rb.box,
-                               rb.height, rb.arrived);
-            hipLaunchKernelGGL(lbvh_number_init_kernel, per_inner, blk, 0, sm, rb.number, n - 1, append_base);
-            hipLaunchKernelGGL(lbvh_number_kernel, dim3(1), dim3(64), 0, sm, (const LbvhNode*)rb.lnodes, n, hot, rb.number, rb.queue);
-            hipLaunchKernelGGL(lbvh_emit_kernel, per_inner, blk, 0, sm, (const LbvhNode*)rb.lnodes, n, (const uint32_t*)rb.number, (const float*)rb.box,
-                               (const float*)box_cur, nodes_dev);
-            HIP_TRY_SYNC(hipGetLastError(), sm);
-            root_ref = hot > 0 ? 0u : append_base;      // (lbvh_number_kernel: the root is the first record in breadth-first order)
-            HIP_TRY_SYNC(hipMemcpyAsync(&height0, rb.height, 4, hipMemcpyDeviceToHost, sm), sm);
-        }
-    }
-    float* root_dev = box_cur + (size_t)n * 8;
-    hipLaunchKernelGGL(refit_root_kernel, dim3(1), dim3(1), 0, sm, (const DevNode*)nodes_dev, root_ref, n, (const float*)box_cur, root_dev);
+    HIP_TRY(hipMemcpyAsync(rb.xforms_stage, scene->xforms_host.data(), scene->xforms_host.size() * sizeof(Word4), hipMemcpyHostToDevice, sm));
+    hipLaunchKernelGGL(refit_entities_kernel, per_entity, blk, 0, sm, ent_live, rb.entities_stage, (const Word4*)rb.xforms_stage, scene->view.meshes, rb.ent_box_stage, n);
+    hipLaunchKernelGGL(lbvh_bounds_kernel, dim3(1), blk, 0, sm, (const float*)rb.ent_box_stage, n, rb.bounds);
+    hipLaunchKernelGGL(lbvh_keys_kernel, per_entity, blk, 0, sm, (const float*)rb.ent_box_stage, n, (const float*)rb.bounds, rb.keys_a);
     HIP_TRY_SYNC(hipGetLastError(), sm);
-    float root[6];
-    HIP_TRY_SYNC(hipMemcpyAsync(root, root_dev, sizeof(root), hipMemcpyDeviceToHost, sm), sm);
+    size_t temp_bytes = rb.sort_temp_bytes;
+    HIP_TRY_SYNC(hipcub::DeviceRadixSort::SortKeys(rb.sort_temp, temp_bytes, rb.keys_a, rb.keys_b, (int)n, 0, 62, sm), sm);
+    hipLaunchKernelGGL(lbvh_permute_kernel, per_entity, blk, 0, sm, (const unsigned long long*)rb.keys_b, n, (const DevEntity*)rb.entities_stage, ent_new,
+                       (const float*)rb.ent_box_stage, box_new, (uint32_t*)nullptr);
+    uint32_t root_ref = RT_REF_LEAF_BIT | ((n - 1u) << RT_REF_COUNT_SHIFT);      // all entities in one leaf ...
+    if (n > RT_LBVH_LEAF) {                                                        // ... or a tree
+        HIP_TRY_SYNC(hipMemsetAsync(rb.arrived, 0, (size_t)(n - 1) * 4, sm), sm);
+        hipLaunchKernelGGL(lbvh_topology_kernel, per_inner, blk, 0, sm, (const unsigned long long*)rb.keys_b, n, rb.lnodes, rb.parent);
+        hipLaunchKernelGGL(lbvh_boxes_kernel, per_entity, blk, 0, sm, (const LbvhNode*)rb.lnodes, (const uint32_t*)rb.parent, n, (const float*)box_new, rb.box,
+                           rb.height, rb.arrived);
+        hipLaunchKernelGGL(lbvh_number_init_kernel, per_inner, blk, 0, sm, rb.number, n - 1, append_base);
+        hipLaunchKernelGGL(lbvh_number_kernel, dim3(1), dim3(64), 0, sm, (const LbvhNode*)rb.lnodes, n, hot, rb.number, rb.queue);
+        HIP_TRY_SYNC(hipGetLastError(), sm);
+        root_ref = hot > 0 ? 0u : append_base;      // (lbvh_number_kernel: the root is the first record in breadth-first order)
+        HIP_TRY_SYNC(hipMemcpyAsync(&height0, rb.height, 4, hipMemcpyDeviceToHost, sm), sm);
+    }
     HIP_TRY(hipStreamSynchronize(sm));
-    // the scene now IS the new tree (entity arrays in key order, TLAS cache slots and appended records rewritten)
-    rb.entities_alt = const_cast<DevEntity*>(scene->view.entities) == ent_cur ? rb.entities_alt : const_cast<DevEntity*>(scene->view.entities);
-    scene->view.entities = ent_cur;
-    scene->view.ent_box = reinterpret_cast<const Word4*>(box_cur);
-    scene->ent_box_dev = box_cur;
+    // traversal stack for the new depth (scene_build.cpp's bound), and what that leaves the node cache
+    const uint32_t stack_entries = height0 + 1u + scene->blas_walk_depth + 2u;
+    const size_t stack_bytes = ((size_t)stack_entries + (scene->view.mesh_entities ? 3 : 0)) * RT_BLOCK * sizeof(uint32_t);
+    uint32_t debug_limit;
+    { std::lock_guard<std::mutex> og(scene->opt_lock); debug_limit = scene->opt.debug_rebuild_stack_limit; }
+    if (stack_bytes > 64 * 1024 || (debug_limit && stack_entries > debug_limit)) {
+        // (a refit of the device-built tree would now find another topology in the build's buffers than the records describe: the next refit must be a rebuild)
+        if (!scene->refit_valid) rb.topology_stale = true;
+        return set_error(RT_E_DEPTH, "rt_scene_rebuild_tlas: the tree over these entities is too deep for the LDS traversal stack (more than 64 levels); the scene is unchanged "
+                                     "(it keeps its previous transforms and tree)");
+    }
+    // ---- phase 2: commit.  From the first of these writes on the old scene is gone; a HIP failure in here (none is expected: the same launches and copies have
+    // succeeded in phase 1) poisons the scene instead of leaving a half-written one in use.
+    auto poisoned = [&](const char* what, hipError_t e) -> int {
+        (void)hipStreamSynchronize(sm);
+        if (scene->dev_error_host) *(volatile uint32_t*)scene->dev_error_host |= RT_DEVERR_POISONED;
+        return set_error(RT_E_HIP, std::string("rt_scene_rebuild_tlas: ") + what + ": " + hipGetErrorString(e) + " - the scene is unusable, create it anew");
+    };
+    hipError_t he;
+    if ((he = hipMemcpyAsync(const_cast<Word4*>(scene->view.xforms), rb.xforms_stage, scene->xforms_host.size() * sizeof(Word4), hipMemcpyDeviceToDevice, sm)) != hipSuccess)
+        return poisoned("copy of the transform records", he);
+    if (n > RT_LBVH_LEAF) {
+        hipLaunchKernelGGL(lbvh_emit_kernel, per_inner, blk, 0, sm, (const LbvhNode*)rb.lnodes, n, (const uint32_t*)rb.number, (const float*)rb.box,
+                           (const float*)box_new, nodes_dev);
+        if ((he = hipGetLastError()) != hipSuccess) return poisoned("lbvh_emit_kernel", he);
+    }
+    float* root_dev = box_new + (size_t)n * 8;
+    hipLaunchKernelGGL(refit_root_kernel, dim3(1), dim3(1), 0, sm, (const DevNode*)nodes_dev, root_ref, n, (const float*)box_new, root_dev);
+    if ((he = hipGetLastError()) != hipSuccess) return poisoned("refit_root_kernel", he);
+    float root[6];
+    if ((he = hipMemcpyAsync(root, root_dev, sizeof(root), hipMemcpyDeviceToHost, sm)) != hipSuccess) return poisoned("copy of the root box", he);
+    if ((he = hipStreamSynchronize(sm)) != hipSuccess) return poisoned("hipStreamSynchronize", he);
+    // the scene now IS the new tree (entity arrays in key order, TLAS cache slots and appended records rewritten); the arrays it used become the next build's output
+    rb.entities_alt = const_cast<DevEntity*>(scene->view.entities);
+    rb.ent_box_alt = scene->ent_box_dev;
+    scene->view.entities = ent_new;
+    scene->view.ent_box = reinterpret_cast<const Word4*>(box_new);
+    scene->ent_box_dev = box_new;
+    scene->refit_valid = false;               // the refit tables of rt_scene_create describe a tree that is gone
+    rb.topology_stale = false;
     scene->view.tlas_root_ref = root_ref;
     for (int k = 0; k < 3; k++) { scene->view.tlas_min[k] = root[k]; scene->view.tlas_max[k] = root[3 + k]; }
-    scene->view.loose_boxes = loose ? 1u : 0u;
+    scene->view.loose_boxes = 0u;
     scene->view.coc_rel_max = host_coc_rel_max(scene->camera, scene->view.tlas_min, scene->view.tlas_max, n > 0);
-    // traversal stack for the new depth (scene_build.cpp's bound), and what that leaves the node cache
-    scene->view.stack_entries = height0 + 1u + scene->blas_walk_depth + 2u;
-    const size_t stack_bytes = ((size_t)scene->view.stack_entries + (scene->view.mesh_entities ? 3 : 0)) * RT_BLOCK * sizeof(uint32_t);
+    scene->view.stack_entries = stack_entries;
     const size_t block_budget = (size_t)160 * 1024 * RT_BLOCK / (256 * RT_WAVES_PER_SIMD);
     const size_t room = stack_bytes < block_budget ? (block_budget - stack_bytes) / RT_NODE_CACHE_STRIDE : 0;
     scene->view.lds_nodes = (uint32_t)std::min<size_t>(scene->lds_nodes_built, room);
     scene->stack_lds_bytes = stack_bytes;
     scene->lds_bytes = stack_bytes + (size_t)scene->view.lds_nodes * RT_NODE_CACHE_STRIDE;
     scene->info.tlas_depth = height0;
-    if (stack_bytes > 64 * 1024)
-        return set_error(RT_E_DEPTH, "rt_scene_rebuild_tlas: the tree over these entities is too deep for the LDS traversal stack (more than 64 levels); create the scene anew");
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_kernel<true, true, true, true, true, true, true>, RT_BLOCK, scene->lds_bytes) == hipSuccess && per_cu >= 1) {
         hipDeviceProp_t prop;
@@ -2296,8 +2471,10 @@ int rt_strip_rows(uint32_t height, uint32_t strip_height, uint32_t strip_first, 
     return (int)rows;
 }
 
-int rt_render_strips_device(RtScene* scene, const RtSettings* st, uint32_t strip_height, uint32_t strip_first, uint32_t strip_period,
-                            uint64_t seed, void* rgb_dev, void* rgba_dev, void* counters_dev, void* stream) {
+// Body of rt_render_strips_device.  interleave_dst: write every strip to its own rows of a full frame of pitch st->width (which may live on another
+// device with peer access) instead of packing the strips.
+static int render_strips_on(RtScene* scene, const RtSettings* st, uint32_t strip_height, uint32_t strip_first, uint32_t strip_period,
+                            uint64_t seed, void* rgb_dev, void* rgba_dev, bool interleave_dst, void* counters_dev, hipStream_t sm) {
     if (!st) return set_error(RT_E_INVALID, "null argument");
     const int rows = rt_strip_rows(st->height, strip_height, strip_first, strip_period);
     if (rows < 0) return set_error(RT_E_INVALID, "rt_render_strips_device: strip_height and strip_period must be > 0, strip_first < strip_period");
@@ -2310,7 +2487,6 @@ int rt_render_strips_device(RtScene* scene, const RtSettings* st, uint32_t strip
     if (rc) return rc;
     std::lock_guard<std::mutex> g(scene->lock);
     HIP_TRY(hipSetDevice(scene->device));
-    hipStream_t sm = (hipStream_t)stream;
     const uint32_t npix = local.width * local.height;
     Workspace& ws = scene->shared;
     if ((rc = ws.accum.ensure((size_t)npix * 12))) return rc;
@@ -2319,9 +2495,15 @@ int rt_render_strips_device(RtScene* scene, const RtSettings* st, uint32_t strip
                             (unsigned long long*)counters_dev, sm, il);
     if (rc) return rc;
     hipLaunchKernelGGL(finish_kernel, dim3((npix + 255) / 256), dim3(256), 0, sm, (const float*)ws.accum.p, local.width, 0u, 0u, local.width, npix,
-                       (float)st->samples_per_pixel, (float*)rgb_dev, (uint8_t*)rgba_dev, local.width, 0u, 0u);
+                       (float)st->samples_per_pixel, (float*)rgb_dev, (uint8_t*)rgba_dev, local.width, 0u, 0u,
+                       interleave_dst ? il.strip_h : 0u, il.period_rows, il.first_row);
     HIP_TRY(hipGetLastError());
     return RT_OK;
+}
+
+int rt_render_strips_device(RtScene* scene, const RtSettings* st, uint32_t strip_height, uint32_t strip_first, uint32_t strip_period,
+                            uint64_t seed, void* rgb_dev, void* rgba_dev, void* counters_dev, void* stream) {
+    return render_strips_on(scene, st, strip_height, strip_first, strip_period, seed, rgb_dev, rgba_dev, false, counters_dev, (hipStream_t)stream);
 }
 
 int rt_accumulate_chunk_device(RtScene* scene, const RtSettings* st, const RtRenderChunk* ch, uint64_t seed, uint32_t sample_first,
@@ -2333,6 +2515,202 @@ int rt_accumulate_chunk_device(RtScene* scene, const RtSettings* st, const RtRen
     HIP_TRY(hipSetDevice(scene->device));
     return enqueue_accumulate(scene, scene->shared, st, ch, seed, sample_first, sample_count, (float*)accum_dev, st->width, ch->left, ch->top, false,
                               (unsigned long long*)counters_dev, (hipStream_t)stream);
+}
+
+// ---- cancellation and progress inside a call (src/render.rs:131,149,156-158) ------------------------------------------------------
+int rt_scene_cancel(RtScene* scene, int cancel) {
+    if (!scene) return set_error(RT_E_INVALID, "null scene");
+    if (scene->device == RT_DEVICE_HOST_ONLY || !scene->dev_error_host) return set_error(RT_E_NO_DEVICE, "scene was created host-only");
+    __atomic_store_n((uint32_t*)scene->cancel_host(), cancel ? 1u : 0u, __ATOMIC_SEQ_CST);      // host-mapped: the waves see it at their next poll
+    return RT_OK;
+}
+
+int rt_scene_progress(const RtScene* scene, uint64_t* blocks_done, uint64_t* blocks_total) {
+    if (!scene) return set_error(RT_E_INVALID, "null scene");
+    if (scene->device == RT_DEVICE_HOST_ONLY || !scene->dev_error_host) return set_error(RT_E_NO_DEVICE, "scene was created host-only");
+    const uint64_t total = scene->progress_total.load();
+    uint64_t done = *scene->progress_host();
+    if (done > total) done = total;
+    if (blocks_done) *blocks_done = done;
+    if (blocks_total) *blocks_total = total;
+    return RT_OK;
+}
+
+// ---- one frame on N GPUs, composited on the first (src/render.rs:186-224 across devices) -------------------------------------------
+// total[p] = acc_0[p] + acc_1[p] + ... in rank order (the deterministic sum of raytracer_amd/dist.py: reduce_accumulators "ordered")
+__global__ void sum_ranks_kernel(float* total, const float* const* parts, uint32_t n_parts, uint64_t n_floats) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_floats) return;
+    float v = parts[0][i];
+    for (uint32_t r = 1; r < n_parts; r++) v = v + parts[r][i];
+    total[i] = v;
+}
+
+int rt_render_frame_multi(RtScene* const* scenes, uint32_t n_scenes, const RtSettings* st, uint32_t mode, uint64_t seed,
+                          void* rgb_dev0, void* rgba_dev0, RtRayCounters* counters) {
+    if (!scenes || n_scenes == 0 || !st) return set_error(RT_E_INVALID, "rt_render_frame_multi: null argument");
+    if (n_scenes > RT_MAX_DEVICES) return set_error(RT_E_LIMIT, "rt_render_frame_multi: more scene replicas than RT_MAX_DEVICES");
+    if (mode != RT_MULTI_TILES && mode != RT_MULTI_SPP) return set_error(RT_E_INVALID, "rt_render_frame_multi: mode is RT_MULTI_TILES or RT_MULTI_SPP");
+    for (uint32_t i = 0; i < n_scenes; i++) {
+        if (!scenes[i]) return set_error(RT_E_INVALID, "rt_render_frame_multi: null scene");
+        if (scenes[i]->device == RT_DEVICE_HOST_ONLY) return set_error(RT_E_NO_DEVICE, "rt_render_frame_multi: a scene was created host-only");
+        for (uint32_t j = 0; j < i; j++)
+            if (scenes[j] == scenes[i]) return set_error(RT_E_INVALID, "rt_render_frame_multi: the same scene twice (every replica needs its own RtScene: they render at the same time)");
+    }
+    const RtRenderChunk whole{0, 0, st->width, st->height};
+    if (int rc = validate_call(scenes[0], st, &whole)) return rc;
+    RtScene* s0 = scenes[0];
+    const int dev0 = s0->device;
+    const uint64_t npix = (uint64_t)st->width * st->height;
+    static std::mutex multi_lock;                    // one frame at a time per process (the contexts hold per-device streams and buffers)
+    std::lock_guard<std::mutex> mg(multi_lock);
+    // ---- context: streams, events, peer access; rebuilt when the list of replicas changes
+    MultiContext* mc = s0->multi;
+    if (!mc || mc->scenes != std::vector<RtScene*>(scenes, scenes + n_scenes)) {
+        if (mc) { mc->release(); delete mc; s0->multi = nullptr; }
+        mc = new MultiContext();
+        mc->scenes.assign(scenes, scenes + n_scenes);
+        mc->dev.resize(n_scenes);
+        const bool no_peer = getenv("RT_MULTI_NO_PEER") != nullptr;      // tests: force the copy path even where direct writes are possible (read when a context is built)
+        for (uint32_t i = 0; i < n_scenes; i++) {
+            MultiContext::PerDevice& d = mc->dev[i];
+            d.device = scenes[i]->device;
+            hipError_t e = hipSetDevice(d.device);
+            if (e == hipSuccess) e = hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&d.done, hipEventDisableTiming);
+            if (e != hipSuccess) { mc->release(); delete mc; return set_error(RT_E_HIP, std::string("rt_render_frame_multi: stream / event: ") + hipGetErrorString(e)); }
+            d.direct = d.device == dev0;
+            if (!d.direct && !no_peer) {
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, d.device, dev0) == hipSuccess && can) {
+                    e = hipDeviceEnablePeerAccess(dev0, 0);
+                    d.direct = e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled;
+                    (void)hipGetLastError();
+                }
+            }
+            if (no_peer) d.direct = false;
+        }
+        s0->multi = mc;
+    }
+    // ---- per device: enqueue its share on its own stream, from its own host thread (the reference's worker threads, one per GPU)
+    const uint32_t strip_h = 8u;
+    auto work = [&](uint32_t i) {
+        MultiContext::PerDevice& d = mc->dev[i];
+        RtScene* sc = scenes[i];
+        d.rc = RT_OK; d.error.clear(); d.host_counters = RtRayCounters{};
+        auto fail = [&](int rc) { d.rc = rc; d.error = g_error; };
+        auto hip = [&](hipError_t e, const char* what) -> bool { if (e == hipSuccess) return true; set_error(RT_E_HIP, std::string("rt_render_frame_multi: ") + what + ": " + hipGetErrorString(e)); fail(RT_E_HIP); return false; };
+        if (!hip(hipSetDevice(d.device), "hipSetDevice")) return;
+        int rc;
+        if ((rc = d.counters.ensure(sizeof(RtRayCounters)))) return fail(rc);
+        if (!hip(hipMemsetAsync(d.counters.p, 0, sizeof(RtRayCounters), d.stream), "hipMemsetAsync")) return;
+        if (mode == RT_MULTI_TILES) {
+            const int rows = rt_strip_rows(st->height, strip_h, i, n_scenes);
+            if (rows > 0) {
+                if (d.direct) {
+                    // every strip straight to its rows of GPU 0's frame (over this GPU's own xGMI link when it is another device)
+                    if ((rc = render_strips_on(sc, st, strip_h, i, n_scenes, seed, rgb_dev0, rgba_dev0, true, d.counters.p, d.stream))) return fail(rc);
+                } else {
+                    // no peer access: packed strips here, then one copy per strip and output
+                    if (rgb_dev0 && (rc = d.packed_rgb.ensure((size_t)rows * st->width * 12))) return fail(rc);
+                    if (rgba_dev0 && (rc = d.packed_rgba.ensure((size_t)rows * st->width * 4))) return fail(rc);
+                    if ((rc = render_strips_on(sc, st, strip_h, i, n_scenes, seed, rgb_dev0 ? d.packed_rgb.p : nullptr, rgba_dev0 ? d.packed_rgba.p : nullptr, false, d.counters.p, d.stream)))
+                        return fail(rc);
+                    uint32_t local_row = 0;
+                    for (uint64_t top = (uint64_t)i * strip_h; top < st->height; top += (uint64_t)n_scenes * strip_h) {
+                        const uint32_t h = (uint32_t)(st->height - top < strip_h ? st->height - top : strip_h);
+                        if (rgb_dev0 && !hip(hipMemcpyPeerAsync((char*)rgb_dev0 + top * st->width * 12, dev0, (char*)d.packed_rgb.p + (size_t)local_row * st->width * 12, d.device,
+                                                               (size_t)h * st->width * 12, d.stream), "hipMemcpyPeerAsync")) return;
+                        if (rgba_dev0 && !hip(hipMemcpyPeerAsync((char*)rgba_dev0 + top * st->width * 4, dev0, (char*)d.packed_rgba.p + (size_t)local_row * st->width * 4, d.device,
+                                                                (size_t)h * st->width * 4, d.stream), "hipMemcpyPeerAsync")) return;
+                        local_row += h;
+                    }
+                }
+            }
+        } else {
+            // this replica's range of whole sample segments of the full frame (raytracer_amd/dist.py: sample_range_of_rank)
+            const uint64_t seg = RT_SAMPLE_SEGMENT, segs = (st->samples_per_pixel + seg - 1) / seg;
+            const uint64_t lo = segs * i / n_scenes * seg, hi_ = segs * (i + 1) / n_scenes * seg, hi = hi_ < st->samples_per_pixel ? hi_ : st->samples_per_pixel;
+            if ((rc = d.accum.ensure(npix * 12))) return fail(rc);
+            if (!hip(hipMemsetAsync(d.accum.p, 0, npix * 12, d.stream), "hipMemsetAsync")) return;
+            if (hi > lo && (rc = rt_accumulate_chunk_device(sc, st, &whole, seed, (uint32_t)lo, (uint32_t)(hi - lo), d.accum.p, d.counters.p, d.stream))) return fail(rc);
+            if (d.device != dev0) {          // the accumulator goes to GPU 0 (a peer copy; staged through the host where peer access is missing)
+                if (!hip(hipMemcpyPeerAsync(d.staging.p, dev0, d.accum.p, d.device, npix * 12, d.stream), "hipMemcpyPeerAsync")) return;
+            }
+        }
+        if (!hip(hipMemcpyAsync(&d.host_counters, d.counters.p, sizeof(RtRayCounters), hipMemcpyDeviceToHost, d.stream), "hipMemcpyAsync")) return;
+        hip(hipEventRecord(d.done, d.stream), "hipEventRecord");
+    };
+    if (mode == RT_MULTI_SPP) {
+        // staging buffers live on GPU 0: allocate them before the workers start
+        HIP_TRY(hipSetDevice(dev0));
+        for (uint32_t i = 0; i < n_scenes; i++)
+            if (mc->dev[i].device != dev0) { if (int rc = mc->dev[i].staging.ensure(npix * 12)) return rc; }
+        if (int rc = mc->total.ensure(npix * 12 + (size_t)n_scenes * sizeof(float*))) return rc;
+    }
+    {
+        std::vector<std::thread> threads;
+        for (uint32_t i = 1; i < n_scenes; i++) threads.emplace_back(work, i);
+        work(0);
+        for (auto& t : threads) t.join();
+    }
+    // ---- drain every stream (also after a failure: nothing may still write the caller's buffers when this returns)
+    int first_rc = RT_OK; std::string first_error;
+    for (uint32_t i = 0; i < n_scenes; i++) {
+        MultiContext::PerDevice& d = mc->dev[i];
+        (void)hipSetDevice(d.device);
+        const hipError_t e = hipStreamSynchronize(d.stream);
+        if (d.rc == RT_OK && e != hipSuccess) { d.rc = RT_E_HIP; d.error = std::string("rt_render_frame_multi: hipStreamSynchronize: ") + hipGetErrorString(e); }
+        if (d.rc != RT_OK && first_rc == RT_OK) { first_rc = d.rc; first_error = d.error; }
+    }
+    if (first_rc != RT_OK) return set_error(first_rc, first_error);
+    HIP_TRY(hipSetDevice(dev0));
+    if (mode == RT_MULTI_SPP) {
+        // sum in replica order on GPU 0, then col / spp and v3_to_rgba (implementation.rs:659, src/rgba.rs:6-12)
+        std::vector<const float*> parts(n_scenes);
+        for (uint32_t i = 0; i < n_scenes; i++) parts[i] = (const float*)(mc->dev[i].device == dev0 ? mc->dev[i].accum.p : mc->dev[i].staging.p);
+        const float** parts_dev = (const float**)((char*)mc->total.p + npix * 12);
+        hipStream_t s = mc->dev[0].stream;
+        HIP_TRY_SYNC(hipMemcpyAsync(parts_dev, parts.data(), n_scenes * sizeof(float*), hipMemcpyHostToDevice, s), s);
+        const uint64_t nf = npix * 3;
+        hipLaunchKernelGGL(sum_ranks_kernel, dim3((uint32_t)((nf + 255) / 256)), dim3(256), 0, s, (float*)mc->total.p, (const float* const*)parts_dev, n_scenes, nf);
+        HIP_TRY_SYNC(hipGetLastError(), s);
+        const uint32_t n = (uint32_t)npix;
+        hipLaunchKernelGGL(finish_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const float*)mc->total.p, n, 0u, 0u, n, n, (float)st->samples_per_pixel,
+                           (float*)rgb_dev0, (uint8_t*)rgba_dev0, n, 0u, 0u, 0u, 0u, 0u);
+        HIP_TRY_SYNC(hipGetLastError(), s);
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    for (uint32_t i = 0; i < n_scenes; i++) {
+        if (int rc = check_device_error(scenes[i])) return rc;
+        if (*scenes[i]->cancel_host() != 0u) return set_error(RT_E_CANCELLED, "rt_render_frame_multi: cancelled (rt_scene_cancel); the frame holds unfinished pixels");
+    }
+    if (counters)
+        for (uint32_t i = 0; i < n_scenes; i++) {
+            const RtRayCounters& c = mc->dev[i].host_counters;
+            counters->primary += c.primary; counters->secondary += c.secondary; counters->shadow += c.shadow; counters->samples += c.samples;
+        }
+    return RT_OK;
+}
+
+int rt_render_frame_multi_host(RtScene* const* scenes, uint32_t n_scenes, const RtSettings* st, uint32_t mode, uint64_t seed,
+                               float* rgb_out, uint8_t* rgba_out, RtRayCounters* counters) {
+    if (!scenes || n_scenes == 0 || !scenes[0] || !st) return set_error(RT_E_INVALID, "rt_render_frame_multi_host: null argument");
+    RtScene* s0 = scenes[0];
+    if (s0->device == RT_DEVICE_HOST_ONLY) return set_error(RT_E_NO_DEVICE, "rt_render_frame_multi_host: a scene was created host-only");
+    const RtRenderChunk whole{0, 0, st->width, st->height};
+    if (int rc = validate_call(s0, st, &whole)) return rc;
+    const size_t npix = (size_t)st->width * st->height;
+    std::lock_guard<std::mutex> g(s0->multi_frame_lock);
+    HIP_TRY(hipSetDevice(s0->device));
+    int rc;
+    if (rgb_out && (rc = s0->multi_frame_rgb.ensure(npix * 12))) return rc;
+    if (rgba_out && (rc = s0->multi_frame_rgba.ensure(npix * 4))) return rc;
+    if ((rc = rt_render_frame_multi(scenes, n_scenes, st, mode, seed, rgb_out ? s0->multi_frame_rgb.p : nullptr, rgba_out ? s0->multi_frame_rgba.p : nullptr, counters))) return rc;
+    HIP_TRY(hipSetDevice(s0->device));
+    if (rgb_out) HIP_TRY(hipMemcpy(rgb_out, s0->multi_frame_rgb.p, npix * 12, hipMemcpyDeviceToHost));
+    if (rgba_out) HIP_TRY(hipMemcpy(rgba_out, s0->multi_frame_rgba.p, npix * 4, hipMemcpyDeviceToHost));
+    return RT_OK;
 }
 
 int rt_resolve_device(int device, const void* accum_dev, uint64_t n_pixels, uint32_t spp, void* rgb_dev, void* rgba_dev, void* stream) {

@@ -53,6 +53,7 @@ void render_thread(uint32_t id, std::shared_ptr<std::atomic<bool>> cancel, std::
             const auto frame_time = std::chrono::steady_clock::now();
             RtRayCounters rays{};
             const int rc = (*work.render)(chunk, buffer, rays);
+            if (rc == RT_E_CANCELLED && cancel->load()) return true;      // the token reached into the running call: a normal end (render.rs:149)
             if (rc != RT_OK) { error = std::string("chunk render failed: ") + rt_last_error(); return false; }
             const auto elapsed = std::chrono::steady_clock::now() - frame_time;
             { RenderThreadMessage m; m.kind = RenderThreadMessage::FrameUpdated; m.chunk = chunk; m.buffer = std::move(buffer); if (!result_sender->send(std::move(m))) return false; }
@@ -68,8 +69,9 @@ void render_thread(uint32_t id, std::shared_ptr<std::atomic<bool>> cancel, std::
 
 }  // namespace
 
-std::unique_ptr<RenderJobWorkerHandle> start_background_render_threads(uint32_t render_thread_count) {
+std::unique_ptr<RenderJobWorkerHandle> start_background_render_threads(uint32_t render_thread_count, std::vector<RtScene*> scenes) {
     auto h = std::make_unique<RenderJobWorkerHandle>();
+    h->scenes = std::move(scenes);
     h->cancel = std::make_shared<std::atomic<bool>>(false);
     h->work_sender = std::make_shared<Channel<RenderWork>>((size_t)render_thread_count * 3);   // flume::bounded(n * 3)
     h->result_receiver = std::make_shared<Channel<RenderThreadMessage>>();                     // flume::unbounded()
@@ -83,8 +85,11 @@ std::unique_ptr<RenderJobWorkerHandle> start_background_render_threads(uint32_t 
 
 void RenderJobWorkerHandle::stop() {
     if (cancel) cancel->store(true);
+    for (RtScene* s : scenes) (void)rt_scene_cancel(s, 1);       // ends the chunk calls that are running on the GPU
     if (work_sender) work_sender->close();
     for (auto& t : thread_handles) if (t.handle.joinable()) t.handle.join();
+    for (RtScene* s : scenes) (void)rt_scene_cancel(s, 0);       // every call has returned: the scenes are usable again
+    scenes.clear();                                              // (stop() runs again from the destructor, when the scenes may be gone)
 }
 
 // render.rs:39-81

@@ -8,8 +8,10 @@
 //   start_background_render_threads            render.rs:186-224
 //   RgbaBuffer                                 src/rgba.rs:14-54
 // The one deliberate difference: the worker's per-pixel loop (render.rs:148-159)
-// is ONE call of rt_render_chunk per chunk, so cancellation and progress happen at
-// chunk granularity.
+// is ONE call of rt_render_chunk per chunk.  The reference checks its cancellation
+// token per pixel (render.rs:149): stop() therefore also cancels the scenes the job
+// renders on (rt_scene_cancel), which ends a chunk call that is running within
+// milliseconds; progress inside a chunk is rt_scene_progress.
 #pragma once
 #include <atomic>
 #include <chrono>
@@ -114,11 +116,12 @@ struct RenderJobWorkerHandle {                   // render.rs:179-184
     std::shared_ptr<Channel<RenderWork>> work_sender;
     std::shared_ptr<Channel<RenderThreadMessage>> result_receiver;
     std::vector<RenderThread> thread_handles;
-    void stop();                                 // cancel + disconnect + join
+    std::vector<RtScene*> scenes;                // the scenes the chunk renderer uses: stop() cancels the calls running on them
+    void stop();                                 // cancel (token + running GPU calls) + disconnect + join, then re-arm the scenes
     ~RenderJobWorkerHandle() { stop(); }
 };
 
-std::unique_ptr<RenderJobWorkerHandle> start_background_render_threads(uint32_t render_thread_count);
+std::unique_ptr<RenderJobWorkerHandle> start_background_render_threads(uint32_t render_thread_count, std::vector<RtScene*> scenes = {});
 
 enum class RenderJobUpdateResult { Updated, ErrorRenderThreadsStopped };
 

@@ -24,13 +24,17 @@ struct Options {
     uint64_t seed = RNG_SEED;
     std::vector<int> devices{0};
     bool self_test = false, list = false;
+    std::string multi;                 // "tiles" / "spp": one rt_render_frame_multi_host call instead of the chunk job
+    int cancel_after_ms = -1;          // >= 0: stop the job after this many milliseconds (exercises the cancellation path)
 };
 
 int usage() {
     fprintf(stderr,
             "usage: rt_render [--scene NAME] [--params \"Key=v;Key=v\"] [--mesh-dir DIR] [--width W] [--height H] [--spp N]\n"
             "                 [--depth D] [--chunks CXxCY] [--threads T] [--seed S] [--devices G[,G...]] [--lens-radius R] [--fov F]\n"
-            "                 [--out frame.ppm] [--list] [--self-test]\n"
+            "                 [--out frame.ppm] [--list] [--self-test] [--multi tiles|spp] [--cancel-after-ms N]\n"
+            "  --multi      the frame in ONE call on all --devices (rt_render_frame_multi_host) instead of the chunk job\n"
+            "  --cancel-after-ms  stop the job after N ms: running chunk calls are cancelled on the GPU (rt_scene_cancel)\n"
             "  --self-test  exercises the job machinery with a synthetic per-chunk pattern instead of the GPU\n");
     return 2;
 }
@@ -58,6 +62,8 @@ bool parse(int argc, char** argv, Options& o) {
             for (const char* p = v; *p;) { o.devices.push_back(atoi(p)); while (*p && *p != ',') p++; if (*p == ',') p++; }
             if (o.devices.empty()) return false;
         }
+        else if (a == "--multi") { o.multi = v; if (o.multi != "tiles" && o.multi != "spp") return false; }
+        else if (a == "--cancel-after-ms") o.cancel_after_ms = atoi(v);
         else if (a == "--lens-radius") o.lens_radius = (float)atof(v);
         else if (a == "--fov") o.fov = (float)atof(v);
         else if (a == "--chunks") { if (sscanf(v, "%ux%u", &o.chunks_x, &o.chunks_y) != 2) return false; }
@@ -116,15 +122,62 @@ int main(int argc, char** argv) {
         renderer = hip_chunk_renderer(scenes, settings, o.seed);
     }
 
+    if (!o.multi.empty() && !o.self_test) {
+        // the whole frame in one call on every device: the worker-thread pool of src/render.rs:186-224 across GPUs
+        RgbaBuffer frame(o.width, o.height);
+        RtRayCounters rays{};
+        const auto t0 = std::chrono::steady_clock::now();
+        const int rc = rt_render_frame_multi_host(scenes.data(), (uint32_t)scenes.size(), &settings, o.multi == "tiles" ? RT_MULTI_TILES : RT_MULTI_SPP, o.seed,
+                                                  nullptr, frame.data.data(), &rays);
+        const double wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        int status = 0;
+        if (rc != RT_OK) { fprintf(stderr, "rt_render: %s\n", rt_last_error()); status = 1; }
+        if (status == 0 && !o.out.empty()) {
+            FILE* f = fopen(o.out.c_str(), "wb");
+            if (!f) { fprintf(stderr, "rt_render: cannot write %s\n", o.out.c_str()); status = 1; }
+            else {
+                fprintf(f, "P6\n%u %u\n255\n", o.width, o.height);
+                for (size_t i = 0; i < (size_t)o.width * o.height; i++) fwrite(frame.data.data() + i * 4, 1, 3, f);
+                fclose(f);
+            }
+        }
+        if (status == 0) {
+            const uint64_t total = rays.primary + rays.secondary + rays.shadow;
+            printf("{\"scene\": \"%s\", \"width\": %u, \"height\": %u, \"spp\": %u, \"max_reflections\": %u, \"multi\": \"%s\", \"replicas\": %zu, "
+                   "\"wall_ms\": %.3f, \"rays\": {\"primary\": %llu, \"secondary\": %llu, \"shadow\": %llu, \"samples\": %llu}, "
+                   "\"mrays_per_s\": %.3f, \"fnv1a\": \"%016llx\"}\n",
+                   o.scene.c_str(), o.width, o.height, o.spp, o.depth, o.multi.c_str(), scenes.size(), wall_ms, (unsigned long long)rays.primary,
+                   (unsigned long long)rays.secondary, (unsigned long long)rays.shadow, (unsigned long long)rays.samples,
+                   wall_ms > 0 ? (double)total / wall_ms / 1e3 : 0.0, (unsigned long long)fnv1a(frame.data));
+        }
+        for (RtScene* sc : scenes) rt_scene_destroy(sc);
+        if (builder) rt_builder_destroy(builder);
+        return status;
+    }
+
     RenderJob job;
     job.render_args = std::make_shared<const ChunkRenderer>(std::move(renderer));
     job.chunks = chunks;
-    job.worker_handle = start_background_render_threads(o.threads);
+    job.worker_handle = start_background_render_threads(o.threads, scenes);
     job.started = std::chrono::steady_clock::now();
 
     RgbaBuffer frame(o.width, o.height);
     int status = 0;
+    bool cancelled = false; double stop_ms = 0.0;
     while (!job.is_work_completed()) {                                               // the UI's per-frame poll, job_running.rs
+        if (o.cancel_after_ms >= 0 &&
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - job.started).count() >= (double)o.cancel_after_ms) {
+            // the user pressed "cancel" (src/app.rs drops the job): token, running GPU calls, join
+            uint64_t done = 0, total = 0;
+            if (!scenes.empty()) (void)rt_scene_progress(scenes[0], &done, &total);
+            const auto t0 = std::chrono::steady_clock::now();
+            job.worker_handle->stop();
+            stop_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            job.update();
+            printf("{\"cancelled\": true, \"after_ms\": %d, \"stop_ms\": %.3f, \"chunks_completed\": %zu, \"chunks\": %zu, \"blocks_done\": %llu, \"blocks_total\": %llu}\n",
+                   o.cancel_after_ms, stop_ms, job.completed_chunk_count, job.chunks.size(), (unsigned long long)done, (unsigned long long)total);
+            cancelled = true; break;
+        }
         if (job.update() == RenderJobUpdateResult::ErrorRenderThreadsStopped) {
             fprintf(stderr, "rt_render: render threads stopped: %s\n", job.first_error.c_str());
             status = 1; break;
@@ -132,6 +185,11 @@ int main(int argc, char** argv) {
         for (auto& u : job.updates) frame.blit(u.first.left, u.first.top, u.second);
         job.updates.clear();
         if (!job.is_work_completed()) std::this_thread::sleep_for(std::chrono::microseconds(200));
+    }
+    if (cancelled) {
+        for (RtScene* sc : scenes) rt_scene_destroy(sc);
+        if (builder) rt_builder_destroy(builder);
+        return 0;
     }
     if (status == 0) {
         job.update();                                                                // drain the last FrameUpdated messages

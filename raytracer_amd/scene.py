@@ -268,7 +268,8 @@ class Scene:
         return rc
 
     OPTIONS = {"lens_sampler": _ffi.RT_OPT_LENS_SAMPLER, "fine_split": _ffi.RT_OPT_FINE_SPLIT, "round_units": _ffi.RT_OPT_ROUND_UNITS,
-               "lens_coc_px": _ffi.RT_OPT_LENS_COC_PX, "debug_stack_entries": _ffi.RT_OPT_DEBUG_STACK_ENTRIES}
+               "lens_coc_px": _ffi.RT_OPT_LENS_COC_PX, "debug_stack_entries": _ffi.RT_OPT_DEBUG_STACK_ENTRIES,
+               "debug_rebuild_stack_limit": _ffi.RT_OPT_DEBUG_REBUILD_STACK_LIMIT}
 
     def set_option(self, name, value):
         """rt_scene_set_option: "lens_sampler" 0 = the reference's independent lens draws / 1 = stratified (default);
@@ -334,6 +335,17 @@ class Scene:
         self._check(self._lib.rt_accumulate_chunk_device(self._h, C.byref(settings.c), C.byref(chunk), seed,
                                                          sample_first, sample_count, accum_ptr, counters_ptr, stream))
 
+    def cancel(self, cancel=True):
+        """rt_scene_cancel: stop (True) every running or enqueued launch on this scene / re-arm it (False).  The reference's
+        cancellation token (src/render.rs:131,149), callable from another thread while a render call blocks."""
+        self._check(self._lib.rt_scene_cancel(self._h, 1 if cancel else 0))
+
+    def progress(self):
+        """rt_scene_progress: (blocks handed out so far - an estimate -, blocks of the call in flight)."""
+        done, total = C.c_uint64(), C.c_uint64()
+        self._check(self._lib.rt_scene_progress(self._h, C.byref(done), C.byref(total)))
+        return done.value, total.value
+
     def profile_enable(self, enable=True):
         self._check(self._lib.rt_scene_profile_enable(self._h, 1 if enable else 0))
 
@@ -353,6 +365,18 @@ class Scene:
         self._check(self._lib.rt_primary_hits(self._h, C.byref(settings.c), C.byref(chunk), t.ctypes.data,
                                               n.ctypes.data, e.ctypes.data, tri.ctypes.data))
         return t, n, e, tri
+
+
+def render_frame_multi(scenes, settings, mode, seed, rgb_ptr0, rgba_ptr0):
+    """rt_render_frame_multi: one frame on len(scenes) replicas (one Scene per GPU), composited in the first one's device
+    memory.  mode: _ffi.RT_MULTI_TILES or _ffi.RT_MULTI_SPP.  Returns the summed RtRayCounters."""
+    lib = _ffi.load_hip()
+    handles = (C.c_void_p * len(scenes))(*[s._h for s in scenes])
+    counters = RtRayCounters()
+    rc = lib.rt_render_frame_multi(handles, len(scenes), C.byref(settings.c), mode, seed, rgb_ptr0, rgba_ptr0, C.byref(counters))
+    if rc < 0:
+        raise RtError(rc, lib.rt_last_error().decode())
+    return counters
 
 
 def sample_segment():

@@ -71,7 +71,7 @@ def test_primary_hits_match_oracle(name, w, h, params):
     st = RenderSettings(w, h, 8, 1)
     exact, cover = check_primary(scene, oracle, st, RenderChunk(0, 0, w, h))
     print(f"{name}: {exact * 100:.3f}% of t bit-identical, {cover * 100:.1f}% pixels hit")
-    assert exact > 0.999
+    assert exact == 1.0
 
 
 def test_ties_between_coincident_faces_go_to_the_reference_winner():
@@ -133,6 +133,27 @@ def test_image_matches_oracle(name, w, h, spp, depth, lens_mode):
     assert abs(cn.shadow - rcn.rays.shadow) <= max(4, 2e-3 * rcn.rays.shadow)
     # bytes: (255*c) as u8 flips on a last-ulp difference only
     assert (np.abs(rgba.astype(int) - ref_rgba.astype(int)) > 1).mean() <= IMAGE_OUTLIER_FRAC
+
+
+def test_baseline_config_1_at_its_own_size(lens_mode):
+    """BASELINE configs[0] exactly: the weekend scene at 400 x 225, 16 spp, max depth 8, lens radius 0.1, seed 12345 - image for image
+    against the oracle, under both lens samplers.  Bound: the flip model of tests/test_gpu_flips.py allows 1e-3 x 8 x 16 = 12.8 % of the
+    pixels; observed and asserted: 0.5 %."""
+    w, h, spp, depth = 400, 225, 16, 8
+    b, scene, oracle = make("Random Spheres", w, h)
+    st, ch = RenderSettings(w, h, depth, spp), RenderChunk(0, 0, w, h)
+    rng_mode = use_lens_mode(scene, lens_mode)
+    rgb, rgba, cn = scene.render_chunk(st, ch, seed=12345)
+    ref, ref_rgba, rcn = oracle.render_chunk(st, ch, rng_mode, 12345, sum_segment=sample_segment())
+    out, mean, mx = check_image(rgb, ref, outlier_frac=5e-3)
+    print(f"C1 {lens_mode}: outliers {out:.5f} mean {mean:.2e} max {mx:.2e}; rays gpu {cn.primary}/{cn.secondary}/{cn.shadow} "
+          f"oracle {rcn.rays.primary}/{rcn.rays.secondary}/{rcn.rays.shadow}")
+    assert cn.samples == w * h * spp == rcn.rays.samples and cn.primary == rcn.rays.primary == w * h * spp
+    assert abs(cn.secondary - rcn.rays.secondary) <= 5e-3 * rcn.rays.secondary and abs(cn.shadow - rcn.rays.shadow) <= 5e-3 * rcn.rays.shadow
+    assert (np.abs(rgba.astype(int) - ref_rgba.astype(int)) > 1).mean() <= 5e-3
+    exact, _ = check_primary(scene, oracle, RenderSettings(w, h, depth, 1), ch)
+    assert exact == 1.0
+    scene.close()
 
 
 def test_scene_controls_reach_the_scene():

@@ -84,3 +84,31 @@ def test_threads_and_chunks_assemble_the_one_call_frame(tmp_path, name, params):
     r = info["rays"]
     assert (r["primary"], r["secondary"], r["shadow"], r["samples"]) == (cn.primary, cn.secondary, cn.shadow, cn.samples)
     assert sum(info["chunks_per_thread"]) == 16
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["tiles", "spp"])
+def test_multi_frame_call_of_the_harness_equals_the_chunk_job(tmp_path, mode):
+    """--multi: the frame in ONE rt_render_frame_multi_host call over three replicas (all on GPU 0 here) instead of the chunk job."""
+    args = ["--scene", "Mesh", "--width", "200", "--height", "112", "--spp", "16", "--seed", "12345"]
+    job, img_job, _ = run(args + ["--chunks", "4x4", "--threads", "3", "--devices", "0"], tmp_path)
+    one, img_one, _ = run(args + ["--devices", "0,0,0", "--multi", mode], tmp_path)
+    assert one["replicas"] == 3 and one["multi"] == mode and one["rays"] == job["rays"]
+    if mode == "tiles":
+        assert np.array_equal(img_one, img_job) and one["fnv1a"] == job["fnv1a"]
+    else:          # another association of the same segment sums: a byte may differ by one where 255 c sits on an integer
+        assert np.abs(img_one.astype(np.int16) - img_job.astype(np.int16)).max() <= 1
+
+
+@pytest.mark.gpu
+def test_cancelling_a_job_ends_the_gpu_calls_that_are_running(tmp_path):
+    """RenderJobWorkerHandle::stop() = the reference's cancellation (src/render.rs:131,149): the token AND the chunk calls running on the GPU.
+    One 4K chunk of the 900-instance scene at 512 spp runs over a second when left alone."""
+    p = subprocess.run([EXE, "--scene", "Doot Doot", "--params", "Count=30;Spacing=30", "--width", "3840", "--height", "2160", "--spp", "512", "--chunks", "1x1",
+                        "--threads", "1", "--cancel-after-ms", "300"], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    info = json.loads(p.stdout.strip().splitlines()[-1])
+    print(info)
+    assert info["cancelled"] is True and info["chunks_completed"] == 0
+    assert info["stop_ms"] < 100.0                                  # cancel + drain + the D2H copy of the (unfinished) 4K frame + join
+    assert 0 < info["blocks_done"] < info["blocks_total"]

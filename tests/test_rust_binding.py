@@ -17,19 +17,17 @@ SCALARS = {"float": "f32", "double": "f64", "uint32_t": "u32", "int32_t": "i32",
 
 
 def c_type_to_rust(c):
-    """'const RtMeshTri*' -> '*const RtMeshTri', 'void*' -> '*mut c_void', 'uint32_t' -> 'u32'"""
-    c = c.strip()
-    ptr = c.endswith("*")
-    if ptr:
-        c = c[:-1].strip()
-    const = c.startswith("const ")
-    if const:
-        c = c[len("const "):].strip()
-    base = SCALARS.get(c, c)
-    if ptr:
-        return ("*const " if const else "*mut ") + base
-    assert not const, c
-    return base
+    """'const RtMeshTri*' -> '*const RtMeshTri', 'void*' -> '*mut c_void', 'uint32_t' -> 'u32', 'RtScene* const*' -> '*const *mut RtScene'"""
+    c = " ".join(c.replace("*", " * ").split())
+    if c.endswith("*"):
+        inner = c[:-1].strip()
+        if inner.endswith("const"):                      # T* const*: pointer to a const pointer
+            return "*const " + c_type_to_rust(inner[:-len("const")])
+        if inner.startswith("const ") and "*" not in inner:
+            return "*const " + c_type_to_rust(inner[len("const "):])
+        return "*mut " + c_type_to_rust(inner)
+    assert not c.startswith("const "), c
+    return SCALARS.get(c, c)
 
 
 def strip_c_comments(text):

@@ -8,7 +8,7 @@ TAG=$1
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/stats.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra-configs > $OUT/stats.log 2>&1
 echo "stats ok"
 for w in weekend-1080p-256spp dreadnaught-1080p-128spp meshdemo-4k-64spp dootdoot-4k-64spp; do
   rm -rf $OUT/pmc_$w
