@@ -56,8 +56,8 @@
 #define RT_QUEUES 16u            /* block counters per launch, one cache line each */
 #endif
 #define RT_MAX_REFLECTIONS 31u
-#ifndef RT_CANCEL_POLL
-#define RT_CANCEL_POLL 4u        /* a wave reads the cancel word at every 4th block claim (power of two) */
+#ifndef RT_CANCEL_POLL_BLOCKS
+#define RT_CANCEL_POLL_BLOCKS 64u   /* the first wave of every 64th workgroup reads the cancel word at its block claims (power of two) */
 #endif
 #ifdef RT_PHASE_TIME            /* (make time: a flavour of the diagnostics build) */
 #define RT_PHASE_STATS
@@ -718,7 +718,6 @@ render_kernel(const DevSceneView S, const RenderParams P) {
 
     uint32_t n_primary = 0, n_secondary = 0, n_shadow = 0, n_samples = 0;
     uint32_t queue = (blockIdx.x * (RT_BLOCK / 64u) + (threadIdx.x >> 6)) % RT_QUEUES;      // this wave's current block counter
-    uint32_t claims = 0;                                                                    // (wave-uniform) block claims of this wave so far
 #if defined(RT_PHASE_STATS) && !defined(RT_PHASE_TIME)
     uint32_t ph_lanes[PH_COUNT] = {}, ph_waves[PH_COUNT] = {};
 #endif
@@ -775,17 +774,18 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                 // next one when that is exhausted, so the hand-out order stays "expensive first".
                 const uint32_t total_blocks = total_items >> 6;          // pix_slots is a multiple of 64
                 uint32_t blk = total_blocks;
-                // Cancellation (the reference checks its token per work item and per pixel, src/render.rs:131,149): every RT_CANCEL_POLL-th claim of a
-                // wave - and its first - lane 0 reads the scene's host-mapped cancel word (one uncached read over the host link, hidden behind the
-                // other waves of the SIMD); a cancelled wave claims nothing more, so the launch drains within one block per wave.
-                bool polled = false, cancelled = false;
-                if ((claims++ & (RT_CANCEL_POLL - 1u)) == 0u) {
+                // Cancellation (the reference checks its token per work item and per pixel, src/render.rs:131,149).  A read of the scene's host-mapped
+                // cancel word crosses the host link and costs microseconds - done by every wave at every 4th claim it halved the headline frame rate
+                // (10 M reads per second).  So ONE wave of every 64th workgroup is a poller: at each of its claims lane 0 reads the word, and when it is
+                // set the poller exhausts all RT_QUEUES block counters (one atomic each): every later claim of every wave then comes back empty and
+                // the launch drains within one block per wave.  The other waves pay nothing.
+                const bool poller = (blockIdx.x & (RT_CANCEL_POLL_BLOCKS - 1u)) == 0u && threadIdx.x < 64u;
+                if (poller) {
                     uint32_t c = 0;
                     if (lane == 0) c = __hip_atomic_load(P.cancel_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    cancelled = __builtin_amdgcn_readfirstlane(c) != 0u;
-                    polled = true;
+                    if (__builtin_amdgcn_readfirstlane(c) != 0u && lane < RT_QUEUES) atomicOr(P.block_counter + lane * 16u, 0x80000000u);      // (idempotent: several pollers do this)
                 }
-                for (uint32_t tries = 0; tries < RT_QUEUES && blk >= total_blocks && !cancelled; tries++) {
+                for (uint32_t tries = 0; tries < RT_QUEUES && blk >= total_blocks; tries++) {
                     uint32_t idx = 0;
                     if (lane == 0) idx = atomicAdd(P.block_counter + queue * 16u, 1u);
                     idx = __builtin_amdgcn_readfirstlane(idx);
@@ -793,8 +793,8 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                     if (blk >= total_blocks) { blk = total_blocks; queue = (queue + 1u) % RT_QUEUES; }
                 }
                 // progress (src/render.rs:156-158 sends a snapshot every 800 ms): the queues advance evenly, so the number of the block just claimed
-                // is about the number of blocks handed out; plain stores, last writer wins - an estimate, not a count
-                if (polled && lane == 0 && blk < total_blocks) __hip_atomic_store(P.progress_word, P.progress_base + blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                // is about the number of blocks handed out; the pollers store it (plain stores, last writer wins - an estimate, not a count)
+                if (poller && lane == 0 && blk < total_blocks) __hip_atomic_store(P.progress_word, P.progress_base + blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 if (blk >= total_blocks) state = FINISHED;
                 else {
                     // Block numbering: first every unit of each tile whose rays hit something, tile after
