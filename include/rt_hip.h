@@ -269,6 +269,22 @@ int rt_scene_update_transforms(RtScene* scene, const RtV3* translations, uint64_
 int rt_scene_rebuild_tlas(RtScene* scene, const RtV3* translations, uint64_t translation_count,
                           const RtRotation* rotations, uint64_t rotation_count, void* stream);
 
+/* Deforming meshes: new vertex positions (and uvs / texture keys) for ONE mesh of an existing scene, same triangle count, and a NEW tree
+ * over them built on the device.  The reference builds a mesh's BVH on the CPU whenever a MeshObject is made (MeshBvhRoot::new,
+ * raytracer-impl/src/shapes/mesh.rs:84-90, over bvh.rs:129-188); a mesh that moves every frame would pay that - and a whole
+ * rt_scene_create - every frame.  `tris` is the mesh as rt_scene_create takes it (RtMesh.tris, original triangle order; host memory).
+ * On the device: triangle boxes (MeshTri::calculate_bounds, mesh.rs:127-133) -> Morton keys -> rocPRIM radix sort -> triangle records
+ * in key order (the precomputed cross(b - a, c - a) of mesh.rs:22-24 with the host build's operations) -> a linear BVH over them
+ * (raytracer_amd/csrc/tlas_build.h; leaves of up to two triangles, like the reference's) -> two-box records into the mesh's slots of
+ * the LDS node cache and behind the scene's records -> the mesh's root box -> boxes of its instances and the TLAS boxes above them
+ * refitted (as rt_scene_update_transforms does).  Like rt_scene_rebuild_tlas this sits behind the NEAREST-HIT gate, not the bit-exact
+ * one: the tree is not the reference's, so a candidate is pruned by other boxes; every triangle test is the reference's, exact ties in
+ * t keep the visit ranks of the tree rt_scene_create built (by original triangle index).  Enqueued on `stream`, then waits for it.  No
+ * render call on this scene may be in flight.  The first call per mesh allocates (about 330 bytes per triangle; the first rebuild of any
+ * kind on a scene also re-allocates the node array with room for every rebuilt tree).  RT_E_DEPTH / RT_E_LIMIT are found before anything
+ * a render call reads is written; rt_scene_bvh_order keeps reporting the trees of rt_scene_create. */
+int rt_scene_rebuild_blas(RtScene* scene, uint32_t mesh_index, const RtMeshTri* tris, uint64_t tri_count, void* stream);
+
 /* Switches of the sampler and of the launch schedule of one scene (no reference counterpart except
  * RT_OPT_LENS_SAMPLER 0).  Takes effect for calls that start afterwards.  Defaults can be preset through the
  * environment, read once in rt_scene_create: RT_LENS_STRATIFY, RT_FINE_SPLIT, RT_ROUND_UNITS, RT_LENS_COC. */
@@ -302,12 +318,13 @@ int rt_scene_set_option(RtScene* scene, uint32_t option, double value);
  *   seed     : replaces XorShiftRng::seed_from_u64(12345) (render.rs:142) by
  *              the key of a counter-based RNG addressed (seed,x,y,sample,node):
  *              the image does not depend on chunking or GPU count.  The two
- *              lens draws of a sample (implementation.rs:649-650) are stratified
- *              inside every complete group of 16 samples (4 x 4 cells over the lens
- *              square, one sample per cell; 4 x 2 cells for a complete group of 8
- *              after the last of them): same expectation as the reference's
- *              independent draws, less noise (RT_OPT_LENS_SAMPLER 0 selects the
- *              reference's distribution).
+ *              lens draws of a sample (implementation.rs:649-650) are stratified:
+ *              8 x 8 cells over the lens square inside every complete group of 64
+ *              samples, one sample per cell; 4 x 4 cells inside every complete group
+ *              of 16 after the last of those; 4 x 2 cells for a complete group of 8
+ *              after that: same expectation as the reference's independent draws,
+ *              less noise (RT_OPT_LENS_SAMPLER 0 selects the reference's
+ *              distribution).
  *   counters : nullable; rays are ADDED to it.
  * Host pointers; the call blocks until the pixels are in the buffers.
  * Limits (RT_E_LIMIT): image sides <= 65535, max_reflections <= 31, at most 2^28

@@ -269,6 +269,7 @@ extern "C" {
     pub fn rt_scene_destroy(scene: *mut RtScene);
     pub fn rt_scene_update_transforms(scene: *mut RtScene, translations: *const RtV3, translation_count: u64, rotations: *const RtRotation, rotation_count: u64, stream: *mut c_void) -> c_int;
     pub fn rt_scene_rebuild_tlas(scene: *mut RtScene, translations: *const RtV3, translation_count: u64, rotations: *const RtRotation, rotation_count: u64, stream: *mut c_void) -> c_int;
+    pub fn rt_scene_rebuild_blas(scene: *mut RtScene, mesh_index: u32, tris: *const RtMeshTri, tri_count: u64, stream: *mut c_void) -> c_int;
     pub fn rt_scene_set_option(scene: *mut RtScene, option: u32, value: f64) -> c_int;
     pub fn rt_render_chunk(scene: *mut RtScene, settings: *const RtSettings, chunk: *const RtRenderChunk, seed: u64, rgb_out: *mut f32, rgba_out: *mut u8, counters: *mut RtRayCounters) -> c_int;
     pub fn rt_render_chunk_device(scene: *mut RtScene, settings: *const RtSettings, chunk: *const RtRenderChunk, seed: u64, rgb_dev: *mut c_void, rgba_dev: *mut c_void, pitch_pixels: u32, out_x: u32, out_y: u32, counters_dev: *mut c_void, stream: *mut c_void) -> c_int;
@@ -389,6 +390,12 @@ impl GpuScene {
         let (mut done, mut total) = (0u64, 0u64);
         check(unsafe { rt_scene_progress(self.handle, &mut done, &mut total) })?;
         Ok((done, total))
+    }
+
+    /// A deforming mesh: new vertex positions for mesh `mesh_index` (same triangle count); its tree is rebuilt on the device and the
+    /// TLAS above its instances refitted (`MeshBvhRoot::new`, mesh.rs:84-90, per frame on the CPU in the reference).
+    pub fn rebuild_mesh(&mut self, mesh_index: u32, tris: &[RtMeshTri]) -> Result<(), GpuError> {
+        check(unsafe { rt_scene_rebuild_blas(self.handle, mesh_index, tris.as_ptr(), tris.len() as u64, std::ptr::null_mut()) })
     }
 
     pub fn as_ptr(&self) -> *mut RtScene {

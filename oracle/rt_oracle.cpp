@@ -1011,11 +1011,17 @@ V3 cast_one_sample(TraceCtx& cx, const RtSettings& st, uint32_t x, uint32_t y, R
         float r0 = rng.next_f32(), r1 = rng.next_f32();
         // ORC_RNG_XORSHIFT_CHUNK and ORC_RNG_COUNTER stop here: the reference uses the two draws as they are (:649-652).
         // ORC_RNG_COUNTER_STRATIFIED - NOT reference semantics, the product's default sampler (RT_OPT_LENS_SAMPLER 1):
-        // the lens samples are stratified, sample s in cell s mod 16 of a 4 x 4 grid over the lens square inside
-        // complete groups of 16 samples (s mod 8 of 4 x 2 cells in a complete segment of 8 after them),
+        // the lens samples are stratified: inside complete groups of 64 samples, sample s lies in one of 8 x 8 cells over the
+        // lens square (s mod 16 names the 4 x 4 cell, bits 4 and 5 of s the quarter of it); after them, in cell s mod 16 of a
+        // 4 x 4 grid inside complete groups of 16 samples (s mod 8 of 4 x 2 cells in a complete segment of 8 after those),
         // jittered inside the cell.  Same expectation, less noise.
         if (!rng.stratified) { }
-        else if ((rng.sample / 16u + 1u) * 16u <= st.samples_per_pixel) {
+        else if ((rng.sample / 64u + 1u) * 64u <= st.samples_per_pixel) {
+            const uint32_t s = rng.sample;                   // complete group of 64 samples: 8 x 8 cells
+            const uint32_t cx = 2u * (s & 3u) + ((s >> 4) & 1u), cy = 2u * ((s >> 2) & 3u) + ((s >> 5) & 1u);
+            r0 = ((float)cx + r0) * 0.125f;
+            r1 = ((float)cy + r1) * 0.125f;
+        } else if ((rng.sample / 16u + 1u) * 16u <= st.samples_per_pixel) {
             const uint32_t cell = rng.sample & 15u;          // complete group of 16 samples: 4 x 4 cells
             r0 = ((float)(cell & 3u) + r0) * 0.25f;
             r1 = ((float)(cell >> 2) + r1) * 0.25f;

@@ -40,8 +40,9 @@ enum {
      * purpose); independent of chunking.  The product in RT_OPT_LENS_SAMPLER 0.    */
     ORC_RNG_COUNTER = 1,
     /* NOT a restatement of the reference: ORC_RNG_COUNTER plus the product's
-     * stratified lens sampler (the two lens draws of sample s are placed in cell
-     * s mod 16 of a 4 x 4 grid over the lens square; include/rt_hip.h,
+     * stratified lens sampler (the two lens draws of sample s are placed in one of
+     * 8 x 8 cells over the lens square inside complete groups of 64 samples, of
+     * 4 x 4 inside complete groups of 16 after them; include/rt_hip.h,
      * rt_render_chunk).  The product's default, RT_OPT_LENS_SAMPLER 1.  The one
      * place the oracle follows the product instead of the reference; it exists so
      * that the default configuration can be compared pixel by pixel too.          */

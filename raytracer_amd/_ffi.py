@@ -182,6 +182,7 @@ HIP_PROTOTYPES = {
     "rt_scene_update_transforms": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p]),
     "rt_scene_rebuild_tlas": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p]),
     "rt_scene_profile_read": (C.c_int, [C.c_void_p, _P(C.c_double), _P(C.c_uint64)]),
+    "rt_scene_rebuild_blas": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p]),
     "rt_render_frame_multi": (C.c_int, [_P(C.c_void_p), C.c_uint32, _P(RtSettings), C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p,
                                         _P(RtRayCounters)]),
     "rt_render_frame_multi_host": (C.c_int, [_P(C.c_void_p), C.c_uint32, _P(RtSettings), C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p,

@@ -56,6 +56,10 @@
 #define RT_QUEUES 16u            /* block counters per launch, one cache line each */
 #endif
 #define RT_MAX_REFLECTIONS 31u
+#ifndef RT_LENS_CELLS
+#define RT_LENS_CELLS 64         /* lens strata of the product's sampler: 64 (8 x 8 cells over complete groups of 64 samples, then 4 x 4 over groups of 16;
+                                    measured: mesh_demo 4K x 1024 spp +7.6 %) or 16 (round 2's sampler: 4 x 4 only; the oracle's stratified mode follows 64) */
+#endif
 #ifndef RT_CANCEL_POLL_BLOCKS
 #define RT_CANCEL_POLL_BLOCKS 64u   /* the first wave of every 64th workgroup reads the cancel word at its block claims (power of two) */
 #endif
@@ -817,10 +821,14 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                     {
                         // the units of the block: 8 (2^k) consecutive ones, or - lens-cell rounds over whole groups of 16
                         // units - every second one of 16, so that the 8 samples of a round share one of the 16 lens cells of
-                        // their 16-sample groups.  blk_unit = first unit; blk_lens = round shape | unit stride shift << 1 | pixel group << 2
-                        const uint32_t k = P.round_units_shift, pairs = (DOF && blk_lens && (P.unit_count & 15u) == 0u) ? 1u : 0u;
-                        blk_lens |= (pairs << 1) | ((unit_local & ((1u << k) - 1u)) << 2);
-                        blk_unit = ((unit_local >> (k + pairs)) << (k + pairs)) + (pairs & (unit_local >> 3));
+                        // their 16-sample groups.  blk_unit = first unit; blk_lens = round shape | unit stride shift << 1 (two bits) | pixel group << 3
+                        // (RT_LENS_CELLS 64: every 8th unit of 64, where the launch holds whole groups of 64 units - the 8 x 8 lens cells of groups of 64 samples)
+                        const uint32_t k = P.round_units_shift;
+                        uint32_t t = 0u;
+                        if (DOF && blk_lens) t = (RT_LENS_CELLS == 64 && (P.unit_count & 63u) == 0u && (P.unit_first & 63u) == 0u) ? 3u : ((P.unit_count & 15u) == 0u ? 1u : 0u);
+                        const uint32_t m = unit_local >> k;
+                        blk_lens |= (t << 1) | ((unit_local & ((1u << k) - 1u)) << 3);
+                        blk_unit = t ? ((m >> t) << (k + t)) + (m & ((1u << t) - 1u)) : (m << k);
                     }
                     round_next = 0u; s = RT_NONE;         // the block's rays are dealt to the lanes round by round, below
                     state = NEED_SAMPLE;
@@ -1000,7 +1008,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
             const uint32_t g_shift = lens ? 3u : 6u - l_shift - k_shift;                    // log2(pixels per round)
             const uint32_t q = lane & ((1u << g_shift) - 1u), j = lane >> g_shift;
             const uint32_t u_in = lens ? j : j >> l_shift, jj = lens ? 0u : j & (P.unit_len - 1u);
-            const uint32_t sub = blk_lens >> 2, unit_local = blk_unit + (u_in << ((blk_lens >> 1) & 1u));
+            const uint32_t sub = blk_lens >> 3, unit_local = blk_unit + (u_in << ((blk_lens >> 1) & 3u));
             const uint32_t x0 = blk_xy0 & 0xffffu, y0 = blk_xy0 >> 16;
             const uint32_t s_mine = (P.unit_first + unit_local) * P.unit_len + jj;
             const bool s_ok = s_mine >= P.sample_first && s_mine < P.sample_first + P.sample_count;
@@ -1048,11 +1056,18 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                     float lx = 0.0f, ly = 0.0f;
                     if (P.spp > 1) {                                                  // :648-653
                         float r0, r1; rng_pair(P.seed, pxy, s, 0u, PURPOSE_LENS, r0, r1);
-                        // Lens samples are stratified: sample s in cell s mod 16 of a 4 x 4 grid over the lens square
+                        // Lens samples are stratified: inside complete groups of 64 samples, sample s lies in one of 8 x 8 cells over the lens square
+                        // (s mod 16 names the 4 x 4 cell, bits 4 and 5 of s the quarter of it); after them in cell s mod 16 of a 4 x 4 grid
                         // (complete groups of 16 samples; 4 x 2 cells for a complete segment of 8 after them), jittered inside the cell (the reference draws them
                         // independently: same expectation, less noise - and the rays of one sample index of
                         // neighbouring pixels leave the lens close together, see the round shapes above).
                         if (!P.lens_stratify) { }                                           // RT_OPT_LENS_SAMPLER 0: the reference's two independent draws
+#if RT_LENS_CELLS == 64
+                        else if (((s >> 6) + 1u) * 64u <= P.spp) {                         // a complete group of 64 samples: 8 x 8 cells; s mod 16 still names the 4 x 4 cell
+                            const uint32_t cx = 2u * (s & 3u) + ((s >> 4) & 1u), cy = 2u * ((s >> 2) & 3u) + ((s >> 5) & 1u);
+                            r0 = ((float)cx + r0) * 0.125f; r1 = ((float)cy + r1) * 0.125f;
+                        }
+#endif
                         else if (((s >> 4) + 1u) * 16u <= P.spp) {                         // a complete group of 16 samples: 4 x 4 cells
                             const uint32_t cell = s & 15u;
                             r0 = ((float)(cell & 3u) + r0) * 0.25f; r1 = ((float)(cell >> 2) + r1) * 0.25f;
@@ -1781,6 +1796,22 @@ struct RtScene {
         Word4* xforms_stage = nullptr;
         bool topology_stale = false;            // a refused build left ANOTHER topology in lnodes / number than the scene's records: no refit from them
     } rebuild;
+    // rt_scene_rebuild_blas: where each mesh's records and triangles live, and the buffers of its device-side build (allocated by the first call per mesh)
+    uint32_t tlas_walk_depth = 0;
+    std::vector<uint32_t> blas_hot_base, blas_hot_count, blas_walk_depths;
+    std::vector<DevMesh> meshes_host;
+    bool node_room = false;                 // the node array has been re-allocated with room for every rebuilt tree (ensure_node_room)
+    struct BlasRebuild {
+        bool ready = false;
+        RtMeshTri* tris = nullptr;
+        float *box_in = nullptr, *box_sorted = nullptr, *ibox = nullptr, *bounds = nullptr, *root = nullptr;
+        unsigned long long *keys_a = nullptr, *keys_b = nullptr;
+        void* sort_temp = nullptr; size_t sort_temp_bytes = 0;
+        LbvhNode* lnodes = nullptr;
+        uint32_t *parent = nullptr, *height = nullptr, *arrived = nullptr, *number = nullptr, *queue = nullptr, *where = nullptr, *rank_stage = nullptr;
+        DevTriHot* hot_stage = nullptr; DevTriCold* cold_stage = nullptr;
+    };
+    std::vector<BlasRebuild> blas_rebuild;
     // Device-pointer entry points run on the CALLER's stream and share this workspace:
     // `lock` serialises their enqueueing, the caller keeps them on one stream.
     std::mutex lock;
@@ -1904,11 +1935,12 @@ int enqueue_accumulate(RtScene* scene, Workspace& ws, const RtSettings* st, cons
     const uint32_t unit_len = fine ? 1u : RT_SAMPLE_SEGMENT;
     // segments per launch: keep the scratch below ~2 GiB (a 4K frame then still runs 16 units per launch)
     const uint32_t units_per_seg = RT_SAMPLE_SEGMENT / unit_len;
-    const uint64_t partial_cap = ws.partial.fixed ? ws.partial.bytes : (1ull << 31);      // (the static scratch of the no-alloc entry point is what it is)
+    const uint64_t partial_cap = ws.partial.fixed ? ws.partial.bytes : (RT_LENS_CELLS == 64 ? (1ull << 33) : (1ull << 31));      // (the static scratch of the no-alloc entry point is what it is)
     uint32_t batch = (uint32_t)(partial_cap / ((uint64_t)pix_slots * 12ull * units_per_seg));
     if (batch == 0) batch = 1;
     if (batch > nseg) batch = nseg;
-    if (batch >= 16) batch &= ~15u;           // (whole groups of units that share their rounds, see round_units_shift
+    if (RT_LENS_CELLS == 64 && batch >= 64) batch &= ~63u;
+    else if (batch >= 16) batch &= ~15u;      // (whole groups of units that share their rounds, see round_units_shift
     else if (batch > 8) batch = 8;            //  and the lens-cell rounds over groups of 16 units)
     int rc = ws.partial.ensure((size_t)batch * units_per_seg * pix_slots * 12);
     if (rc) return rc;
@@ -2096,6 +2128,8 @@ RtScene* rt_scene_create(const RtSceneDesc* desc, int device) {
     s->xforms_words = flat.xforms.size();
     s->refit_level_start = std::move(flat.refit_level_start);
     s->node_count = flat.nodes.size(); s->tlas_hot_records = flat.tlas_hot_records; s->blas_walk_depth = flat.blas_walk_depth; s->lds_nodes_built = flat.view.lds_nodes;
+    s->tlas_walk_depth = flat.tlas_walk_depth; s->blas_hot_base = flat.blas_hot_base; s->blas_hot_count = flat.blas_hot_count; s->blas_walk_depths = flat.blas_walk_depths;
+    s->meshes_host = flat.meshes; s->blas_rebuild.resize(flat.meshes.size());
     if (flat.refit.empty()) flat.refit.emplace_back();
     if (upload(s, flat.refit, &s->refit_dev)) return fail();
     if (upload(s, flat.ent_box, &s->view.ent_box)) return fail();      // the build's entity boxes; rt_scene_update_transforms recomputes them in place
@@ -2255,6 +2289,72 @@ int rt_render_chunk(RtScene* scene, const RtSettings* st, const RtRenderChunk* c
     return RT_OK;
 }
 
+// Device half of rt_scene_update_transforms (also the last step of rt_scene_rebuild_blas): entity boxes from the transform records and mesh
+// boxes on the device, then the TLAS boxes bottom-up, then the root box; waits for the stream (the host needs the root box).
+static int refit_tlas_on_device(RtScene* scene, hipStream_t sm) {
+    Word4* xforms_dev = const_cast<Word4*>(scene->view.xforms);
+    DevNode* nodes_dev = const_cast<DevNode*>(scene->view.nodes);
+    DevEntity* entities_dev = const_cast<DevEntity*>(scene->view.entities);
+    // device: entity boxes, then the tree bottom-up (one launch per level, deepest first), then the root box
+    const uint32_t n = scene->view.entity_count;
+    if (n == 0) { HIP_TRY(hipStreamSynchronize(sm)); return RT_OK; }      // an empty scene keeps the empty root box of rt_scene_create
+    hipLaunchKernelGGL(refit_entities_kernel, dim3((n + 255) / 256), dim3(256), 0, sm, (const DevEntity*)entities_dev, entities_dev, (const Word4*)xforms_dev, scene->view.meshes,
+                       scene->ent_box_dev, n);
+    HIP_TRY_SYNC(hipGetLastError(), sm);
+    if (scene->refit_valid) {
+        for (size_t l = 0; l + 1 < scene->refit_level_start.size(); l++) {
+            const uint32_t first = scene->refit_level_start[l], count = scene->refit_level_start[l + 1] - first;
+            if (count == 0) continue;
+            hipLaunchKernelGGL(refit_level_kernel, dim3((count + 255) / 256), dim3(256), 0, sm, nodes_dev, scene->refit_dev, first, count, (const float*)scene->ent_box_dev);
+            HIP_TRY_SYNC(hipGetLastError(), sm);
+        }
+    } else if (n > RT_LBVH_LEAF) {
+        // the tree was built on the device (rt_scene_rebuild_tlas): its topology and record numbers are still in the build's buffers, so a refit
+        // is the build without the sort: boxes bottom-up, records rewritten
+        RtScene::TlasRebuild& rb = scene->rebuild;
+        const dim3 blk(256), per_entity((n + 255) / 256), per_inner((n - 1 + 255) / 256);
+        HIP_TRY_SYNC(hipMemsetAsync(rb.arrived, 0, (size_t)(n - 1) * 4, sm), sm);
+        hipLaunchKernelGGL(lbvh_boxes_kernel, per_entity, blk, 0, sm, (const LbvhNode*)rb.lnodes, (const uint32_t*)rb.parent, n, (const float*)scene->ent_box_dev, rb.box,
+                           rb.height, rb.arrived);
+        hipLaunchKernelGGL(lbvh_emit_kernel, per_inner, blk, 0, sm, (const LbvhNode*)rb.lnodes, n, (const uint32_t*)rb.number, (const float*)rb.box,
+                           (const float*)scene->ent_box_dev, nodes_dev);
+        HIP_TRY_SYNC(hipGetLastError(), sm);
+    }
+    float* root_dev = scene->ent_box_dev + (size_t)n * 8;
+    hipLaunchKernelGGL(refit_root_kernel, dim3(1), dim3(1), 0, sm, (const DevNode*)nodes_dev, scene->view.tlas_root_ref, n, (const float*)scene->ent_box_dev, root_dev);
+    HIP_TRY_SYNC(hipGetLastError(), sm);
+    float root[6];
+    HIP_TRY_SYNC(hipMemcpyAsync(root, root_dev, sizeof(root), hipMemcpyDeviceToHost, sm), sm);
+    HIP_TRY(hipStreamSynchronize(sm));
+    for (int k = 0; k < 3; k++) { scene->view.tlas_min[k] = root[k]; scene->view.tlas_max[k] = root[3 + k]; }
+    scene->view.loose_boxes = 0u;      // (transforms with a non-unit rotation axis are refused before they reach the device)
+    scene->view.coc_rel_max = host_coc_rel_max(scene->camera, scene->view.tlas_min, scene->view.tlas_max, n > 0);
+    return RT_OK;
+}
+
+// One re-allocation of the node array with room behind the scene's records for every tree a rebuild can emit: n_entities - 1 records for the TLAS
+// (rt_scene_rebuild_tlas), then tri_count - 1 per mesh (rt_scene_rebuild_blas).  (The old array stays allocated until the scene is destroyed:
+// launches in flight may still read it.)
+static size_t rebuilt_tlas_room(const RtScene* scene) { return scene->view.entity_count > 1 ? scene->view.entity_count - 1 : 1; }
+static size_t rebuilt_blas_base(const RtScene* scene, size_t mesh) {
+    size_t at = scene->node_count + rebuilt_tlas_room(scene);
+    for (size_t m = 0; m < mesh; m++) at += scene->meshes_host[m].w[0].u[2] > 1 ? scene->meshes_host[m].w[0].u[2] - 1 : 1;
+    return at;
+}
+static int ensure_node_room(RtScene* scene, hipStream_t sm) {
+    if (scene->node_room) return RT_OK;
+    const size_t total = rebuilt_blas_base(scene, scene->meshes_host.size());
+    if (total >= ((size_t)1 << 26)) return set_error(RT_E_LIMIT, "rebuilt trees would not fit the 2^26 records the walk can address");
+    DevNode* bigger = nullptr;
+    HIP_TRY(hipMalloc((void**)&bigger, total * sizeof(DevNode)));
+    scene->allocations.push_back(bigger);
+    HIP_TRY(hipMemcpyAsync(bigger, scene->view.nodes, scene->node_count * sizeof(DevNode), hipMemcpyDeviceToDevice, sm));
+    HIP_TRY(hipStreamSynchronize(sm));
+    scene->view.nodes = bigger;           // (same contents)
+    scene->node_room = true;
+    return RT_OK;
+}
+
 int rt_scene_update_transforms(RtScene* scene, const RtV3* translations, uint64_t translation_count, const RtRotation* rotations,
                                uint64_t rotation_count, void* stream) {
     if (!scene) return set_error(RT_E_INVALID, "null scene");
@@ -2278,45 +2378,8 @@ int rt_scene_update_transforms(RtScene* scene, const RtV3* translations, uint64_
         return set_error(RT_E_INVALID, "rt_scene_update_transforms: the last rt_scene_rebuild_tlas on this scene was refused (RT_E_DEPTH) and left its working buffers describing "
                                        "another tree than the scene's; call rt_scene_rebuild_tlas again (or create the scene anew)");
     Word4* xforms_dev = const_cast<Word4*>(scene->view.xforms);
-    DevNode* nodes_dev = const_cast<DevNode*>(scene->view.nodes);
-    DevEntity* entities_dev = const_cast<DevEntity*>(scene->view.entities);
     HIP_TRY(hipMemcpyAsync(xforms_dev, scene->xforms_host.data(), scene->xforms_host.size() * sizeof(Word4), hipMemcpyHostToDevice, sm));
-    // device: entity boxes, then the tree bottom-up (one launch per level, deepest first), then the root box
-    const uint32_t n = scene->view.entity_count;
-    if (n == 0) { HIP_TRY(hipStreamSynchronize(sm)); return RT_OK; }      // an empty scene keeps the empty root box of rt_scene_create
-    hipLaunchKernelGGL(refit_entities_kernel, dim3((n + 255) / 256), dim3(256), 0, sm, (const DevEntity*)entities_dev, entities_dev, (const Word4*)xforms_dev, scene->view.meshes,
-                       scene->ent_box_dev, n);
-    HIP_TRY_SYNC(hipGetLastError(), sm);
-    if (scene->refit_valid) {
-        for (size_t l = 0; l + 1 < scene->refit_level_start.size(); l++) {
-            const uint32_t first = scene->refit_level_start[l], count = scene->refit_level_start[l + 1] - first;
-            if (count == 0) continue;
-            hipLaunchKernelGGL(refit_level_kernel, dim3((count + 255) / 256), dim3(256), 0, sm, nodes_dev, scene->refit_dev, first, count, (const float*)scene->ent_box_dev);
-            HIP_TRY_SYNC(hipGetLastError(), sm);
-        }
-    } else if (n > RT_LBVH_LEAF) {
-        // the tree was built on the device (rt_scene_rebuild_tlas): its topology and record numbers are still in the build's buffers, so a refit
-        // is the build without the sort: boxes bottom-up, records rewritten
-        RtScene::TlasRebuild& rb = scene->rebuild;
-        // (checked BEFORE anything was enqueued, below: moved up)
-        const dim3 blk(256), per_entity((n + 255) / 256), per_inner((n - 1 + 255) / 256);
-        HIP_TRY_SYNC(hipMemsetAsync(rb.arrived, 0, (size_t)(n - 1) * 4, sm), sm);
-        hipLaunchKernelGGL(lbvh_boxes_kernel, per_entity, blk, 0, sm, (const LbvhNode*)rb.lnodes, (const uint32_t*)rb.parent, n, (const float*)scene->ent_box_dev, rb.box,
-                           rb.height, rb.arrived);
-        hipLaunchKernelGGL(lbvh_emit_kernel, per_inner, blk, 0, sm, (const LbvhNode*)rb.lnodes, n, (const uint32_t*)rb.number, (const float*)rb.box,
-                           (const float*)scene->ent_box_dev, nodes_dev);
-        HIP_TRY_SYNC(hipGetLastError(), sm);
-    }
-    float* root_dev = scene->ent_box_dev + (size_t)n * 8;
-    hipLaunchKernelGGL(refit_root_kernel, dim3(1), dim3(1), 0, sm, (const DevNode*)nodes_dev, scene->view.tlas_root_ref, n, (const float*)scene->ent_box_dev, root_dev);
-    HIP_TRY_SYNC(hipGetLastError(), sm);
-    float root[6];
-    HIP_TRY_SYNC(hipMemcpyAsync(root, root_dev, sizeof(root), hipMemcpyDeviceToHost, sm), sm);
-    HIP_TRY(hipStreamSynchronize(sm));
-    for (int k = 0; k < 3; k++) { scene->view.tlas_min[k] = root[k]; scene->view.tlas_max[k] = root[3 + k]; }
-    scene->view.loose_boxes = loose ? 1u : 0u;
-    scene->view.coc_rel_max = host_coc_rel_max(scene->camera, scene->view.tlas_min, scene->view.tlas_max, n > 0);
-    return RT_OK;
+    return refit_tlas_on_device(scene, sm);
 }
 
 // A NEW top-level tree over the moved entities, built on the device (tlas_build.h).
@@ -2334,8 +2397,6 @@ int rt_scene_rebuild_tlas(RtScene* scene, const RtV3* translations, uint64_t tra
     if (n == 0) return RT_OK;                 // an empty scene keeps the empty root box and the never-followed root ref of rt_scene_create
     RtScene::TlasRebuild& rb = scene->rebuild;
     const size_t m = n > 1 ? n - 1 : 1;
-    if (scene->node_count + m >= ((size_t)1 << 26))
-        return set_error(RT_E_LIMIT, "rt_scene_rebuild_tlas: the rebuilt tree's records would not fit the 2^26 records the walk can address");
     if (!rb.ready) {
         // first call: the build's buffers (about 250 bytes per entity) and a node array with room for n - 1 more records
         auto dev_alloc = [&](void** p, size_t bytes) -> int {
@@ -2355,11 +2416,7 @@ int rt_scene_rebuild_tlas(RtScene* scene, const RtV3* translations, uint64_t tra
         rb.sort_temp_bytes = 0;
         HIP_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, rb.sort_temp_bytes, rb.keys_a, rb.keys_b, (int)n, 0, 62, sm));
         if ((rc = dev_alloc(&rb.sort_temp, rb.sort_temp_bytes))) return rc;
-        DevNode* bigger = nullptr;
-        if ((rc = dev_alloc((void**)&bigger, (scene->node_count + m) * sizeof(DevNode)))) return rc;
-        HIP_TRY(hipMemcpyAsync(bigger, scene->view.nodes, scene->node_count * sizeof(DevNode), hipMemcpyDeviceToDevice, sm));
-        HIP_TRY(hipStreamSynchronize(sm));
-        scene->view.nodes = bigger;           // (same contents; the old array stays allocated until the scene is destroyed: launches in flight may still read it)
+        if ((rc = ensure_node_room(scene, sm))) return rc;
         rb.ready = true;
     }
     // host: transform records, as in rt_scene_update_transforms
@@ -2447,6 +2504,7 @@ int rt_scene_rebuild_tlas(RtScene* scene, const RtV3* translations, uint64_t tra
     scene->view.loose_boxes = 0u;
     scene->view.coc_rel_max = host_coc_rel_max(scene->camera, scene->view.tlas_min, scene->view.tlas_max, n > 0);
     scene->view.stack_entries = stack_entries;
+    scene->tlas_walk_depth = height0;
     const size_t block_budget = (size_t)160 * 1024 * RT_BLOCK / (256 * RT_WAVES_PER_SIMD);
     const size_t room = stack_bytes < block_budget ? (block_budget - stack_bytes) / RT_NODE_CACHE_STRIDE : 0;
     scene->view.lds_nodes = (uint32_t)std::min<size_t>(scene->lds_nodes_built, room);
@@ -2515,6 +2573,134 @@ int rt_accumulate_chunk_device(RtScene* scene, const RtSettings* st, const RtRen
     HIP_TRY(hipSetDevice(scene->device));
     return enqueue_accumulate(scene, scene->shared, st, ch, seed, sample_first, sample_count, (float*)accum_dev, st->width, ch->left, ch->top, false,
                               (unsigned long long*)counters_dev, (hipStream_t)stream);
+}
+
+// A NEW tree for ONE mesh whose triangles have moved, built on the device (tlas_build.h), then the TLAS boxes above its instances refitted.
+int rt_scene_rebuild_blas(RtScene* scene, uint32_t mesh_index, const RtMeshTri* tris, uint64_t tri_count, void* stream) {
+    if (!scene || !tris) return set_error(RT_E_INVALID, "rt_scene_rebuild_blas: null argument");
+    if (scene->device == RT_DEVICE_HOST_ONLY) return set_error(RT_E_NO_DEVICE, "scene was created host-only");
+    if (mesh_index >= scene->meshes_host.size()) return set_error(RT_E_INVALID, "rt_scene_rebuild_blas: no such mesh");
+    std::lock_guard<std::mutex> g(scene->lock);
+    HIP_TRY(hipSetDevice(scene->device));
+    hipStream_t sm = (hipStream_t)stream;
+    DevMesh& mh = scene->meshes_host[mesh_index];
+    const uint32_t n = mh.w[0].u[2], tri_base = mh.w[0].u[1];
+    if (tri_count != n) return set_error(RT_E_INVALID, "rt_scene_rebuild_blas: the mesh keeps its triangle count (" + std::to_string(n) + "); a mesh of another size is another scene");
+    if (scene->view.loose_boxes) return set_error(RT_E_INVALID, "rt_scene_rebuild_blas: the scene has entities whose boxes do not bound their hits (non-unit rotation axes): only the reference's own trees reproduce them");
+    if (!scene->refit_valid && scene->rebuild.topology_stale)
+        return set_error(RT_E_INVALID, "rt_scene_rebuild_blas: the last rt_scene_rebuild_tlas on this scene was refused; call it again first (the TLAS refit that follows a mesh rebuild needs its buffers)");
+    RtScene::BlasRebuild& rb = scene->blas_rebuild[mesh_index];
+    const size_t m = n > 1 ? n - 1 : 1;
+    const uint32_t hot = scene->blas_hot_count[mesh_index], hot_base = scene->blas_hot_base[mesh_index];
+    int rc;
+    if (!rb.ready) {
+        // first call for this mesh: the build's buffers (about 330 bytes per triangle), and - once per scene - a node array with room for the new records
+        auto dev_alloc = [&](void** p, size_t bytes) -> int {
+            HIP_TRY(hipMalloc(p, bytes ? bytes : 16));
+            scene->allocations.push_back(*p);
+            return RT_OK;
+        };
+        if ((rc = dev_alloc((void**)&rb.tris, (size_t)n * sizeof(RtMeshTri))) || (rc = dev_alloc((void**)&rb.box_in, ((size_t)n + 1) * 32)) ||
+            (rc = dev_alloc((void**)&rb.box_sorted, ((size_t)n + 1) * 32)) || (rc = dev_alloc((void**)&rb.ibox, m * 32)) || (rc = dev_alloc((void**)&rb.bounds, 64)) ||
+            (rc = dev_alloc((void**)&rb.root, 64)) || (rc = dev_alloc((void**)&rb.keys_a, ((size_t)n + 1) * 8)) || (rc = dev_alloc((void**)&rb.keys_b, ((size_t)n + 1) * 8)) ||
+            (rc = dev_alloc((void**)&rb.lnodes, m * sizeof(LbvhNode))) || (rc = dev_alloc((void**)&rb.parent, (2 * (size_t)n + 1) * 4)) ||
+            (rc = dev_alloc((void**)&rb.height, m * 4)) || (rc = dev_alloc((void**)&rb.arrived, m * 4)) || (rc = dev_alloc((void**)&rb.number, m * 4)) ||
+            (rc = dev_alloc((void**)&rb.queue, ((size_t)hot + 1) * 4)) || (rc = dev_alloc((void**)&rb.where, (size_t)n * 4)) ||
+            (rc = dev_alloc((void**)&rb.rank_stage, (size_t)n * 4)) || (rc = dev_alloc((void**)&rb.hot_stage, (size_t)n * sizeof(DevTriHot))) ||
+            (rc = dev_alloc((void**)&rb.cold_stage, (size_t)n * sizeof(DevTriCold))))
+            return rc;
+        rb.sort_temp_bytes = 0;
+        HIP_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, rb.sort_temp_bytes, rb.keys_a, rb.keys_b, (int)n, 0, 62, sm));
+        if ((rc = dev_alloc(&rb.sort_temp, rb.sort_temp_bytes))) return rc;
+        if ((rc = ensure_node_room(scene, sm))) return rc;
+        rb.ready = true;
+    }
+    // ---- phase 1: the new triangle records, topology and boxes, all in the build's own buffers (nothing a render call reads is written) ----
+    DevNode* nodes_dev = const_cast<DevNode*>(scene->view.nodes);
+    DevTriHot* hot_live = const_cast<DevTriHot*>(scene->view.tri_hot) + tri_base;
+    DevTriCold* cold_live = const_cast<DevTriCold*>(scene->view.tri_cold) + tri_base;
+    uint32_t* rank_live = const_cast<uint32_t*>(scene->view.tri_rank) + tri_base;
+    const uint32_t append_base = (uint32_t)rebuilt_blas_base(scene, mesh_index);
+    const dim3 blk(256), per_tri((n + 255) / 256), per_inner((n > 1 ? n - 1 + 255 : 255) / 256);
+    uint32_t height0 = 0;
+    HIP_TRY(hipMemcpyAsync(rb.tris, tris, (size_t)n * sizeof(RtMeshTri), hipMemcpyHostToDevice, sm));
+    hipLaunchKernelGGL(blas_tri_boxes_kernel, per_tri, blk, 0, sm, (const RtMeshTri*)rb.tris, n, rb.box_in);
+    hipLaunchKernelGGL(lbvh_bounds_kernel, dim3(1), blk, 0, sm, (const float*)rb.box_in, n, rb.bounds);
+    hipLaunchKernelGGL(lbvh_keys_kernel, per_tri, blk, 0, sm, (const float*)rb.box_in, n, (const float*)rb.bounds, rb.keys_a);
+    hipLaunchKernelGGL(blas_where_kernel, per_tri, blk, 0, sm, (const DevTriCold*)cold_live, n, rb.where);
+    HIP_TRY_SYNC(hipGetLastError(), sm);
+    size_t temp_bytes = rb.sort_temp_bytes;
+    HIP_TRY_SYNC(hipcub::DeviceRadixSort::SortKeys(rb.sort_temp, temp_bytes, rb.keys_a, rb.keys_b, (int)n, 0, 62, sm), sm);
+    hipLaunchKernelGGL(blas_permute_kernel, per_tri, blk, 0, sm, (const unsigned long long*)rb.keys_b, n, (const RtMeshTri*)rb.tris, (const float*)rb.box_in, (const uint32_t*)rb.where,
+                       (const uint32_t*)rank_live, rb.hot_stage, rb.cold_stage, rb.rank_stage, rb.box_sorted);
+    uint32_t root_ref = RT_REF_LEAF_BIT | ((n - 1u) << RT_REF_COUNT_SHIFT);      // every triangle in one leaf ...
+    if (n > RT_LBVH_LEAF) {                                                        // ... or a tree
+        HIP_TRY_SYNC(hipMemsetAsync(rb.arrived, 0, (size_t)(n - 1) * 4, sm), sm);
+        hipLaunchKernelGGL(lbvh_topology_kernel, per_inner, blk, 0, sm, (const unsigned long long*)rb.keys_b, n, rb.lnodes, rb.parent);
+        hipLaunchKernelGGL(lbvh_boxes_kernel, per_tri, blk, 0, sm, (const LbvhNode*)rb.lnodes, (const uint32_t*)rb.parent, n, (const float*)rb.box_sorted, rb.ibox, rb.height,
+                           rb.arrived);
+        hipLaunchKernelGGL(lbvh_number_init_kernel, per_inner, blk, 0, sm, rb.number, n - 1, append_base);
+        hipLaunchKernelGGL(lbvh_number_kernel, dim3(1), dim3(64), 0, sm, (const LbvhNode*)rb.lnodes, n, hot, rb.number, rb.queue, hot_base);
+        root_ref = hot > 0 ? hot_base : append_base;
+        HIP_TRY_SYNC(hipMemcpyAsync(&height0, rb.height, 4, hipMemcpyDeviceToHost, sm), sm);
+    }
+    hipLaunchKernelGGL(blas_root_kernel, dim3(1), dim3(1), 0, sm, (const float*)rb.ibox, (const float*)rb.box_sorted, n, rb.root);
+    HIP_TRY_SYNC(hipGetLastError(), sm);
+    float root[6];
+    HIP_TRY_SYNC(hipMemcpyAsync(root, rb.root, sizeof(root), hipMemcpyDeviceToHost, sm), sm);
+    HIP_TRY(hipStreamSynchronize(sm));
+    // the traversal stack the scene needs with this tree in it
+    uint32_t blas_depth = height0;
+    for (size_t k = 0; k < scene->blas_walk_depths.size(); k++) if (k != mesh_index && scene->blas_walk_depths[k] > blas_depth) blas_depth = scene->blas_walk_depths[k];
+    const uint32_t stack_entries = scene->tlas_walk_depth + 1u + blas_depth + 2u;
+    const size_t stack_bytes = ((size_t)stack_entries + (scene->view.mesh_entities ? 3 : 0)) * RT_BLOCK * sizeof(uint32_t);
+    uint32_t debug_limit;
+    { std::lock_guard<std::mutex> og(scene->opt_lock); debug_limit = scene->opt.debug_rebuild_stack_limit; }
+    if (stack_bytes > 64 * 1024 || (debug_limit && stack_entries > debug_limit))
+        return set_error(RT_E_DEPTH, "rt_scene_rebuild_blas: the tree over these triangles is too deep for the LDS traversal stack (more than 64 levels); the scene is unchanged");
+    // ---- phase 2: commit (a HIP failure from here on poisons the scene: it would be half old, half new) ----
+    auto poisoned = [&](const char* what, hipError_t e) -> int {
+        (void)hipStreamSynchronize(sm);
+        if (scene->dev_error_host) *(volatile uint32_t*)scene->dev_error_host |= RT_DEVERR_POISONED;
+        return set_error(RT_E_HIP, std::string("rt_scene_rebuild_blas: ") + what + ": " + hipGetErrorString(e) + " - the scene is unusable, create it anew");
+    };
+    hipError_t he;
+    if ((he = hipMemcpyAsync(hot_live, rb.hot_stage, (size_t)n * sizeof(DevTriHot), hipMemcpyDeviceToDevice, sm)) != hipSuccess) return poisoned("copy of the triangle records", he);
+    if ((he = hipMemcpyAsync(cold_live, rb.cold_stage, (size_t)n * sizeof(DevTriCold), hipMemcpyDeviceToDevice, sm)) != hipSuccess) return poisoned("copy of the triangle records", he);
+    if ((he = hipMemcpyAsync(rank_live, rb.rank_stage, (size_t)n * 4, hipMemcpyDeviceToDevice, sm)) != hipSuccess) return poisoned("copy of the visit ranks", he);
+    if (n > RT_LBVH_LEAF) {
+        hipLaunchKernelGGL(lbvh_emit_kernel, per_inner, blk, 0, sm, (const LbvhNode*)rb.lnodes, n, (const uint32_t*)rb.number, (const float*)rb.ibox, (const float*)rb.box_sorted,
+                           nodes_dev);
+        if ((he = hipGetLastError()) != hipSuccess) return poisoned("lbvh_emit_kernel", he);
+    }
+    DevMesh header = mh;
+    header.w[0].u[3] = root_ref;
+    header.w[1].f[0] = root[0]; header.w[1].f[1] = root[1]; header.w[1].f[2] = root[2]; header.w[1].f[3] = root[3];
+    header.w[2].f[0] = root[4]; header.w[2].f[1] = root[5];
+    if ((he = hipMemcpyAsync(const_cast<DevMesh*>(scene->view.meshes) + mesh_index, &header, sizeof(DevMesh), hipMemcpyHostToDevice, sm)) != hipSuccess)
+        return poisoned("copy of the mesh header", he);
+    if ((he = hipStreamSynchronize(sm)) != hipSuccess) return poisoned("hipStreamSynchronize", he);      // (`header` is a local)
+    mh = header;
+    scene->blas_walk_depths[mesh_index] = height0;
+    scene->blas_walk_depth = blas_depth;
+    scene->info.blas_depth = std::max(scene->info.blas_depth, height0);
+    scene->view.stack_entries = stack_entries;
+    const size_t block_budget = (size_t)160 * 1024 * RT_BLOCK / (256 * RT_WAVES_PER_SIMD);
+    const size_t room = stack_bytes < block_budget ? (block_budget - stack_bytes) / RT_NODE_CACHE_STRIDE : 0;
+    scene->view.lds_nodes = (uint32_t)std::min<size_t>(scene->lds_nodes_built, room);
+    scene->stack_lds_bytes = stack_bytes;
+    scene->lds_bytes = stack_bytes + (size_t)scene->view.lds_nodes * RT_NODE_CACHE_STRIDE;
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_kernel<true, true, true, true, true, true, true>, RT_BLOCK, scene->lds_bytes) == hipSuccess && per_cu >= 1) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, scene->device) == hipSuccess) scene->grid_blocks = prop.multiProcessorCount * per_cu;
+    }
+    // the mesh's box has changed: the boxes of its instances and the TLAS boxes above them follow (the refit of rt_scene_update_transforms)
+    if ((rc = refit_tlas_on_device(scene, sm))) {
+        if (scene->dev_error_host) *(volatile uint32_t*)scene->dev_error_host |= RT_DEVERR_POISONED;
+        return rc;
+    }
+    return RT_OK;
 }
 
 // ---- cancellation and progress inside a call (src/render.rs:131,149,156-158) ------------------------------------------------------

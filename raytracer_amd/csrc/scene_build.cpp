@@ -568,6 +568,7 @@ int build_flat_scene(const RtSceneDesc* d, FlatScene& out, std::string& err) {
         }
         const Emitter& be = *emitters.back();
         if (be.depth > blas_walk_depth) blas_walk_depth = be.depth;
+        out.blas_walk_depths.push_back(be.depth);
         blas_depth = std::max(blas_depth, emitted_depth(t));
         DevMesh& dm = out.meshes[m];
         dm.w[0].u[0] = 0; dm.w[0].u[1] = tri_base; dm.w[0].u[2] = (uint32_t)mesh.tri_count; dm.w[0].u[3] = 0;      // root ref: below
@@ -650,13 +651,14 @@ int build_flat_scene(const RtSceneDesc* d, FlatScene& out, std::string& err) {
                     }
                     out.refit_level_start.push_back((uint32_t)out.refit.size());
                 }
-            } else out.meshes[k - 1].w[0].u[3] = ref;
+            } else { out.meshes[k - 1].w[0].u[3] = ref; out.blas_hot_base.push_back(hot_at); out.blas_hot_count.push_back(hot[k]); }
             hot_at += hot[k]; cold_at += (uint32_t)emitters[k]->en.size() - hot[k];
             emitters[k].reset();
         }
         v.lds_nodes = (uint32_t)n_hot;
         out.tlas_hot_records = hot.empty() ? 0u : hot[0];
         out.blas_walk_depth = blas_walk_depth;
+        out.tlas_walk_depth = tlas_walk_depth;
     }
     out.info.blas_node_count = out.nodes.size() - out.info.tlas_node_count;
     out.info.blas_depth = blas_depth;

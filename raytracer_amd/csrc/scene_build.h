@@ -43,6 +43,10 @@ struct FlatScene {
     // rebuild of the TLAS on the device (rt_scene_rebuild_tlas): the TLAS's share of the LDS node cache (its records [0, tlas_hot_records)),
     // and the deepest BLAS walk (the traversal stack bound is tlas depth + 1 + blas_walk_depth + 2)
     uint32_t tlas_hot_records = 0, blas_walk_depth = 0;
+    // rebuild of one mesh's BLAS on the device (rt_scene_rebuild_blas): the depth of the TLAS walk, and per mesh its share of the LDS node
+    // cache (records [blas_hot_base, + blas_hot_count)) and the depth of its walk
+    uint32_t tlas_walk_depth = 0;
+    std::vector<uint32_t> blas_hot_base, blas_hot_count, blas_walk_depths;
 };
 
 // Host half of rt_scene_update_transforms: the transform records of every entity (layout of FlatScene::xforms) for new

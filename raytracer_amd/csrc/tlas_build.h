@@ -159,13 +159,13 @@ __global__ void lbvh_number_init_kernel(uint32_t* number, uint32_t n_inner, uint
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_inner) number[i] = append_base + i;
 }
-__global__ void lbvh_number_kernel(const LbvhNode* nodes, uint32_t n, uint32_t hot, uint32_t* number, uint32_t* queue /* hot entries */) {
+__global__ void lbvh_number_kernel(const LbvhNode* nodes, uint32_t n, uint32_t hot, uint32_t* number, uint32_t* queue /* hot entries */, uint32_t hot_base = 0u) {
     if (threadIdx.x != 0 || blockIdx.x != 0 || n <= RT_LBVH_LEAF || hot == 0) return;
     uint32_t head = 0, tail = 0;
     queue[tail++] = 0u;                                        // the root (its range is the whole array: > RT_LBVH_LEAF entities here)
     while (head < tail) {
         const uint32_t i = queue[head];
-        number[i] = head++;
+        number[i] = hot_base + head++;
         const LbvhNode nd = nodes[i];
         for (int c = 0; c < 2; c++) {
             const uint32_t ref = c ? nd.right : nd.left;
@@ -201,6 +201,64 @@ __global__ void lbvh_emit_kernel(const LbvhNode* nodes, uint32_t n, const uint32
     w[8] = hi[0][1]; w[9] = hi[1][1]; w[10] = hi[0][2]; w[11] = hi[1][2];
     uint32_t* r = out[number[i]].w[3].u;
     r[0] = refs[0]; r[1] = refs[1]; r[2] = 0u; r[3] = 0u;
+}
+
+// ---- the same build for ONE mesh's triangles (rt_scene_rebuild_blas) ------------------------------------------------------------------
+// The reference builds a mesh's BVH on the CPU whenever a MeshObject is made (MeshBvhRoot::new, mesh.rs:84-90, over bvh.rs:129-188); a mesh
+// whose vertices move every frame would pay that every frame.  Same stages as above over the triangles' boxes (MeshTri::calculate_bounds,
+// mesh.rs:127-133: AABB::from_vertices over a, b, c); leaves are ranges of <= RT_LBVH_LEAF triangles in key order.
+
+// box of every triangle (8 floats: lo.xyz, -, hi.xyz, -), in the order of the caller's array
+__global__ void blas_tri_boxes_kernel(const RtMeshTri* tris, uint32_t n, float* box) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const RtMeshTri t = tris[i];
+    float* o = box + (size_t)i * 8;
+    o[0] = fminf(fminf(t.a.x, t.b.x), t.c.x); o[1] = fminf(fminf(t.a.y, t.b.y), t.c.y); o[2] = fminf(fminf(t.a.z, t.b.z), t.c.z); o[3] = 0.0f;
+    o[4] = fmaxf(fmaxf(t.a.x, t.b.x), t.c.x); o[5] = fmaxf(fmaxf(t.a.y, t.b.y), t.c.y); o[6] = fmaxf(fmaxf(t.a.z, t.b.z), t.c.z); o[7] = 0.0f;
+}
+
+// position (in the mesh's slice of the triangle arrays) of every ORIGINAL triangle index: the visit ranks that decide exact ties in t
+// (mesh.rs:96-98) stay those of the tree rt_scene_create built, whatever order the triangles are stored in
+__global__ void blas_where_kernel(const DevTriCold* cold, uint32_t n, uint32_t* where) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const uint32_t orig = (uint32_t)ldw(cold[p].w + 1).i[3];
+    if (orig < n) where[orig] = p;
+}
+
+// triangle records in key order: hot = a, b, c + cross(b - a, c - a) with the host build's operations (mesh.rs:22-24, types.rs:64-68),
+// cold = uvs, tex_key, original index; rank = the stored visit rank of that original triangle; box permuted alongside
+__global__ void blas_permute_kernel(const unsigned long long* keys, uint32_t n, const RtMeshTri* tris, const float* box_in, const uint32_t* where,
+                                    const uint32_t* rank_old, DevTriHot* hot, DevTriCold* cold, uint32_t* rank, float* box_out) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const uint32_t src = (uint32_t)keys[j];
+    const RtMeshTri t = tris[src];
+    const float abx = t.b.x - t.a.x, aby = t.b.y - t.a.y, abz = t.b.z - t.a.z;
+    const float acx = t.c.x - t.a.x, acy = t.c.y - t.a.y, acz = t.c.z - t.a.z;
+    const float nx = aby * acz - abz * acy, ny = -(abx * acz - abz * acx), nz = abx * acy - aby * acx;
+    float* h = hot[j].w[0].f;
+    h[0] = t.a.x; h[1] = t.a.y; h[2] = t.a.z; h[3] = nx;
+    h[4] = t.b.x; h[5] = t.b.y; h[6] = t.b.z; h[7] = ny;
+    h[8] = t.c.x; h[9] = t.c.y; h[10] = t.c.z; h[11] = nz;
+    Word4* c = cold[j].w;
+    c[0].f[0] = t.a_uv.x; c[0].f[1] = t.a_uv.y; c[0].f[2] = t.b_uv.x; c[0].f[3] = t.b_uv.y;
+    c[1].f[0] = t.c_uv.x; c[1].f[1] = t.c_uv.y; c[1].i[2] = t.tex_key; c[1].i[3] = (int32_t)src;
+    rank[j] = rank_old[where[src]];
+    for (int k = 0; k < 2; k++) *reinterpret_cast<float4*>(box_out + (size_t)j * 8 + 4 * k) = *reinterpret_cast<const float4*>(box_in + (size_t)src * 8 + 4 * k);
+}
+
+// the mesh's root box (DevMesh words 1, 2): the union of all triangle boxes = the two boxes of inner node 0, or - a mesh of <= RT_LBVH_LEAF
+// triangles - of its triangles
+__global__ void blas_root_kernel(const float* inner_box, const float* tri_box, uint32_t n, float* root /* lo.xyz hi.xyz */) {
+    float lo[3], hi[3];
+    if (n > RT_LBVH_LEAF) { for (int k = 0; k < 3; k++) { lo[k] = inner_box[k]; hi[k] = inner_box[4 + k]; } }
+    else {
+        for (int k = 0; k < 3; k++) { lo[k] = tri_box[k]; hi[k] = tri_box[4 + k]; }
+        for (uint32_t i = 1; i < n; i++) for (int k = 0; k < 3; k++) { lo[k] = fminf(lo[k], tri_box[i * 8 + k]); hi[k] = fmaxf(hi[k], tri_box[i * 8 + 4 + k]); }
+    }
+    for (int k = 0; k < 3; k++) { root[k] = lo[k]; root[3 + k] = hi[k]; }
 }
 
 #endif

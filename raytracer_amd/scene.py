@@ -290,6 +290,12 @@ class Scene:
         self._check(self._lib.rt_scene_rebuild_tlas(self._h, C.cast(d.translations, C.c_void_p), d.translation_count,
                                                     C.cast(d.rotations, C.c_void_p), d.rotation_count, stream))
 
+    def rebuild_blas(self, builder, mesh_index, stream=None):
+        """rt_scene_rebuild_blas: take the triangles of mesh `mesh_index` of `builder` (the same mesh, deformed: same triangle count) and
+        build a new tree over them on the device; the boxes of its instances and the TLAS above them are refitted."""
+        mesh = builder.desc().contents.meshes[mesh_index]
+        self._check(self._lib.rt_scene_rebuild_blas(self._h, mesh_index, C.cast(mesh.tris, C.c_void_p), mesh.tri_count, stream))
+
     def info(self):
         out = RtSceneInfo()
         self._check(self._lib.rt_scene_info(self._h, C.byref(out)))
