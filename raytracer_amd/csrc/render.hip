@@ -624,6 +624,7 @@ struct RenderParams {
     float lens_coc_px;                              // classify_kernel: circle of confusion (pixels) from which a tile's rounds go by lens cell
     uint32_t lens_rounds;                           // tiles flagged by classify_kernel may run rounds of one sample index (8 units x 8 pixels)
     uint32_t lens_stratify;                         // 1: stratified lens samples (the product's sampler); 0: two independent draws (implementation.rs:648-653)
+    uint32_t kind_order;                            // 1: the rays of a burst are of ONE kind - shadow rays light by light, then path rays; lanes of a later kind wait
     uint32_t* error_flag;                           // sticky device-side error word (RT_DEVERR_* bits), read back by the host entry points
     const uint32_t* cancel_word;                    // host-mapped: non-zero = rt_scene_cancel; the waves stop claiming blocks (src/render.rs:131,149: the cancellation token)
     uint32_t* progress_word;                        // host-mapped: about how many blocks of the call have been handed out so far (rt_scene_progress)
@@ -720,6 +721,8 @@ render_kernel(const DevSceneView S, const RenderParams P) {
     const uint32_t total_items = P.pix_slots * P.unit_count;
     const uint32_t lane = threadIdx.x & 63u;
 
+    // (counting samples and camera rays on the host instead - both are known per launch - frees two registers and was measured: Dreadnaught +0.5 %, 900 instances +0.8 %,
+    //  mesh_demo -1.1 %, weekend +-0: register allocation moves more than two registers do.  Not adopted.)
     uint32_t n_primary = 0, n_secondary = 0, n_shadow = 0, n_samples = 0;
     uint32_t queue = (blockIdx.x * (RT_BLOCK / 64u) + (threadIdx.x >> 6)) % RT_QUEUES;      // this wave's current block counter
 #if defined(RT_PHASE_STATS) && !defined(RT_PHASE_TIME)
@@ -733,7 +736,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
     // (or, with `tracing` false, has just finished and waits for its shading).
     enum { PATH = 0, SHADOW = 1, NEED_LIGHT = 2, NEED_PATH = 3, NEED_SAMPLE = 4, NEED_BLOCK = 5, FINISHED = 6 };
     int state = NEED_BLOCK;
-    bool tracing = false;
+    bool tracing = false, held = false;      // held: a ray is waiting to start (RT_OPT_KIND_ORDER)
     uint32_t pxy = 0, s = RT_NONE;           // pixel (x | y << 16) and sample index of the lane's current round (RT_NONE: no sample)
     // the wave's current block (wave-uniform): tile, unit, rounds started
     uint32_t blk_tile = 0, blk_unit = 0, round_next = 0, blk_lens = 0;
@@ -836,7 +839,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
             }
             if (__ballot(state != FINISHED) == 0ull) break;      // the wave has no blocks left
         }
-        if (!tracing && state != NEED_BLOCK && state != FINISHED) {
+        if (!tracing && !held && state != NEED_BLOCK && state != FINISHED) {
             // ================= shading of the ray that just finished =====================
             PH(PH_SHADE);
             TM(TM_SHADE);
@@ -1090,7 +1093,18 @@ render_kernel(const DevSceneView S, const RenderParams P) {
         }
         if (!tracing && state != NEED_BLOCK && state != FINISHED) {
             // ================= start the traversal of the new ray ==========================
-            if (state == PATH || state == SHADOW) {
+            // RT_OPT_KIND_ORDER: the rays that start together are of one kind - the shadow rays towards the lowest-numbered light any lane has
+            // waiting, path rays only when no lane has a shadow ray left; the other lanes are held back for a later burst (their order of
+            // operations is unchanged: only the schedule moves, never a pixel).
+            bool go = state == PATH || state == SHADOW;
+            if (go && P.kind_order) {
+                uint32_t first_light = 0xffu;
+                for (uint32_t k = 0; k < S.light_count; k++)
+                    if (__ballot(state == SHADOW && light_k == k) != 0ull) { first_light = k; break; }
+                if (first_light != 0xffu) go = state == SHADOW && light_k == first_light;
+                held = !go;
+            }
+            if (go) {
                 PH(PH_TRACE_INIT);
                 TM(TM_OTHER);
                 const bool shadow = state == SHADOW;
@@ -1155,6 +1169,9 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                         // (32-bit byte offset from the uniform base: one shift instead of a 64-bit shift and add; rt_scene_create refuses scenes of 2^26 records)
                         const Word4* n = reinterpret_cast<const Word4*>(reinterpret_cast<const char*>(S.nodes) + (cur << 6));
                         na = ldw(n); nb = ldw(n + 1); nc = ldw(n + 2); nr = ldw(n + 3);
+#ifdef RT_EXTRA_NODE_LOAD      /* measurement only: what ONE more 16-byte read of the same line costs per node step - the slope along which a 48-byte record would gain */
+                        { const float4 extra = *reinterpret_cast<const volatile float4*>(n + 3); asm volatile("" ::"v"(extra.x), "v"(extra.y), "v"(extra.z), "v"(extra.w)); }
+#endif
                     }
                     float el, er; bool hl, hr;
                     slab2(na, nb, nc, o, inv, t_min, (LOOSE && inst_sp == RT_NONE) ? t_max : best_t, hl, hr, el, er);
@@ -1743,7 +1760,8 @@ struct SceneOptions {
     int lens_stratify = 1;          // RT_OPT_LENS_SAMPLER
     int fine_split = -1;            // RT_OPT_FINE_SPLIT: -1 automatic, 0 whole segments, 1 single samples
     int round_units = 8;            // RT_OPT_ROUND_UNITS
-    float lens_coc_px = 4.0f;       // RT_OPT_LENS_COC_PX (4 px measured best; 3..8 within 1 %)
+    float lens_coc_px = 3.0f;       // RT_OPT_LENS_COC_PX (with 8 x 8 lens cells: mesh_demo 4K x 1024 spp 16 871 / 16 819 / 16 732 / 16 484 / 16 000 Mrays/s at 2 / 3 / 4 / 6 / 8 px, weekend within 0.6 %)
+    int kind_order = 0;             // RT_OPT_KIND_ORDER
     uint32_t debug_stack_entries = 0;   // RT_OPT_DEBUG_STACK_ENTRIES: 0 = what the trees need
     uint32_t debug_rebuild_stack_limit = 0;   // RT_OPT_DEBUG_REBUILD_STACK_LIMIT: rt_scene_rebuild_tlas refuses trees that need more stack entries (0 = the LDS limit)
 };
@@ -1955,6 +1973,7 @@ int enqueue_accumulate(RtScene* scene, Workspace& ws, const RtSettings* st, cons
     P.strip_h = il.strip_h; P.strip_period_rows = il.period_rows; P.strip_first_row = il.first_row;
     P.lens_coc_px = opt.lens_coc_px;      // circle of confusion in pixels from which a tile runs lens-cell rounds (a huge value turns them off)
     P.lens_stratify = opt.lens_stratify ? 1u : 0u;
+    P.kind_order = opt.kind_order ? 1u : 0u;
     P.error_flag = scene->dev_error_dev;
     P.cancel_word = scene->dev_error_dev + 16; P.progress_word = scene->dev_error_dev + 32; P.progress_base = 0;
     {
@@ -2162,6 +2181,7 @@ RtScene* rt_scene_create(const RtSceneDesc* desc, int device) {
     if (const char* e = getenv("RT_FINE_SPLIT")) s->opt.fine_split = atoi(e) != 0;
     if (const char* e = getenv("RT_ROUND_UNITS")) s->opt.round_units = atoi(e);
     if (const char* e = getenv("RT_LENS_COC")) s->opt.lens_coc_px = (float)atof(e);
+    if (const char* e = getenv("RT_KIND_ORDER")) s->opt.kind_order = atoi(e) != 0;
     return s;
 }
 
@@ -2178,6 +2198,9 @@ int rt_scene_set_option(RtScene* scene, uint32_t option, double value) {
         case RT_OPT_ROUND_UNITS:
             if (value != 1.0 && value != 2.0 && value != 4.0 && value != 8.0) return set_error(RT_E_INVALID, "RT_OPT_ROUND_UNITS: 1, 2, 4 or 8");
             scene->opt.round_units = (int)value; return RT_OK;
+        case RT_OPT_KIND_ORDER:
+            if (value != 0.0 && value != 1.0) return set_error(RT_E_INVALID, "RT_OPT_KIND_ORDER: 0 or 1");
+            scene->opt.kind_order = (int)value; return RT_OK;
         case RT_OPT_LENS_COC_PX:
             if (!(value >= 0.0)) return set_error(RT_E_INVALID, "RT_OPT_LENS_COC_PX: a circle of confusion in pixels, >= 0");
             scene->opt.lens_coc_px = (float)value; return RT_OK;

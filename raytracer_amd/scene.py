@@ -269,7 +269,7 @@ class Scene:
 
     OPTIONS = {"lens_sampler": _ffi.RT_OPT_LENS_SAMPLER, "fine_split": _ffi.RT_OPT_FINE_SPLIT, "round_units": _ffi.RT_OPT_ROUND_UNITS,
                "lens_coc_px": _ffi.RT_OPT_LENS_COC_PX, "debug_stack_entries": _ffi.RT_OPT_DEBUG_STACK_ENTRIES,
-               "debug_rebuild_stack_limit": _ffi.RT_OPT_DEBUG_REBUILD_STACK_LIMIT}
+               "debug_rebuild_stack_limit": _ffi.RT_OPT_DEBUG_REBUILD_STACK_LIMIT, "kind_order": _ffi.RT_OPT_KIND_ORDER}
 
     def set_option(self, name, value):
         """rt_scene_set_option: "lens_sampler" 0 = the reference's independent lens draws / 1 = stratified (default);
@@ -290,10 +290,15 @@ class Scene:
         self._check(self._lib.rt_scene_rebuild_tlas(self._h, C.cast(d.translations, C.c_void_p), d.translation_count,
                                                     C.cast(d.rotations, C.c_void_p), d.rotation_count, stream))
 
-    def rebuild_blas(self, builder, mesh_index, stream=None):
-        """rt_scene_rebuild_blas: take the triangles of mesh `mesh_index` of `builder` (the same mesh, deformed: same triangle count) and
-        build a new tree over them on the device; the boxes of its instances and the TLAS above them are refitted."""
-        mesh = builder.desc().contents.meshes[mesh_index]
+    def rebuild_blas(self, builder, mesh_index, builder_mesh_index=None, stream=None):
+        """rt_scene_rebuild_blas: take the triangles of mesh `builder_mesh_index` (default: `mesh_index`) of `builder` (the same mesh,
+        deformed: same triangle count) and build a new tree over them on the device for this scene's mesh `mesh_index`; the boxes of its
+        instances and the TLAS above them are refitted."""
+        d = builder.desc().contents
+        k = mesh_index if builder_mesh_index is None else builder_mesh_index
+        if not 0 <= k < d.mesh_count:
+            raise RtError(_ffi.RT_E_INVALID, f"the builder has no mesh {k}")
+        mesh = d.meshes[k]
         self._check(self._lib.rt_scene_rebuild_blas(self._h, mesh_index, C.cast(mesh.tris, C.c_void_p), mesh.tri_count, stream))
 
     def info(self):

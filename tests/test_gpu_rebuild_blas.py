@@ -157,7 +157,7 @@ def test_rebuild_blas_refusals_leave_the_scene_as_it_was():
         scene.rebuild_blas(scene_with(suzanne[:100]), 0)
     assert e.value.code == _ffi.RT_E_INVALID
     with pytest.raises(RtError, match="no such mesh"):
-        scene.rebuild_blas(a, 7)
+        scene.rebuild_blas(a, 7, builder_mesh_index=0)
     scene.set_option("debug_rebuild_stack_limit", 3)
     with pytest.raises(RtError, match="too deep") as e:
         scene.rebuild_blas(scene_with(wobble(suzanne, 1.0)), 0)

@@ -10,7 +10,7 @@ mkdir -p gpurun_out
 for v in "${vals[@]}"; do
   for w in "${wl[@]}"; do
     export $var=$v
-    timeout -k 10 300 python bench.py --workload $w --no-cpu-baseline --steps 3 --warmup 1 > gpurun_out/ab.json 2> gpurun_out/ab.err || exit 1
+    timeout -k 10 300 python bench.py --workload $w --no-cpu-baseline --no-target-scene --no-extra-configs --steps 3 --warmup 1 > gpurun_out/ab.json 2> gpurun_out/ab.err || exit 1
     python -c "import json; d=json.loads(open('gpurun_out/ab.json').read().strip().splitlines()[-1]); print('$var=$v', d['config']['workload'], d['value'], d['ms_per_step'])"
   done
 done

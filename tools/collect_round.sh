@@ -12,10 +12,10 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/s
 echo "stats ok"
 for w in weekend-1080p-256spp dreadnaught-1080p-128spp meshdemo-4k-64spp dootdoot-4k-64spp; do
   rm -rf $OUT/pmc_$w
-  tools/pmc_passes.sh $OUT/pmc_$w "sq1 sq2 sq3 tcp tcc1 tcc2 ta ta2 grbm" --workload $w --no-target-scene
+  tools/pmc_passes.sh $OUT/pmc_$w "sq1 sq2 sq3 tcp tcc1 tcc2 ta ta2 grbm" --workload $w --no-target-scene --no-extra-configs
   python tools/pmc_summary.py $OUT/pmc_$w render_kernel > $OUT/pmc_$w.json
 done
-for w in weekend-1080p-256spp weekend-400x225-16spp dreadnaught-1080p-128spp dootdoot-4k-64spp meshdemo-4k-1024spp; do
-  timeout -k 10 500 python bench.py --workload $w --steps 3 --warmup 1 --no-target-scene > $OUT/bench_$w.json 2> $OUT/bench_$w.err
+for w in weekend-1080p-256spp weekend-400x225-16spp dreadnaught-1080p-128spp dootdoot-4k-64spp meshdemo-4k-64spp meshdemo-4k-1024spp; do
+  timeout -k 10 500 python bench.py --workload $w --steps 3 --warmup 1 --no-target-scene --no-extra-configs > $OUT/bench_$w.json 2> $OUT/bench_$w.err
   python -c "import json; d=json.loads(open('$OUT/bench_$w.json').read().strip().splitlines()[-1]); print(d['config']['workload'], d['value'], d['ms_per_step'], d['roofline']['frac'], d['cpu_baseline']['value'], d['gpu_over_cpu'], d['roofline']['traversal_mismatch'])"
 done
