@@ -1170,7 +1170,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                         const Word4* n = reinterpret_cast<const Word4*>(reinterpret_cast<const char*>(S.nodes) + (cur << 6));
                         na = ldw(n); nb = ldw(n + 1); nc = ldw(n + 2); nr = ldw(n + 3);
 #ifdef RT_EXTRA_NODE_LOAD      /* measurement only: what ONE more 16-byte read of the same line costs per node step - the slope along which a 48-byte record would gain */
-                        { const float4 extra = *reinterpret_cast<const volatile float4*>(n + 3); asm volatile("" ::"v"(extra.x), "v"(extra.y), "v"(extra.z), "v"(extra.w)); }
+                        { typedef float v4f __attribute__((ext_vector_type(4))); const v4f extra = *reinterpret_cast<const volatile v4f*>(n + 3); asm volatile("" ::"v"(extra.x), "v"(extra.y), "v"(extra.z), "v"(extra.w)); }
 #endif
                     }
                     float el, er; bool hl, hr;
