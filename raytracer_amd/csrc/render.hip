@@ -1458,9 +1458,14 @@ classify_kernel(const DevSceneView S, const RenderParams P, uint32_t n_tiles, ui
     // Round shape of the tile (render_kernel): where the rays of a pixel spread over more than P.lens_coc_px pixels,
     // rounds of one sample index (one lens cell) of 8 neighbouring pixels are more coherent than rounds of one pixel.
     const uint32_t by_lens = (hits > 0.0f && coc > P.lens_coc_px * hits) ? 0x100u : 0u;
-    if (live && k == 0u) {
-        tile_bin[tile] = cls | by_lens;
-        atomicAdd(group_counts + (tile / RT_ORDER_GROUP) * RT_COST_BINS + cls, 1u);      // (at most RT_ORDER_GROUP adds per address)
+    if (live && k == 0u) tile_bin[tile] = cls | by_lens;
+    // class counts of the tile's group, for order_kernel: the four tiles of a wave lie in one group (RT_ORDER_GROUP is a multiple of 4) and are usually of one class,
+    // so one add per wave and class present (one add per TILE, 1 024 to the same address, made this kernel 100 us slower)
+#pragma unroll
+    for (uint32_t c = 0; c < RT_COST_BINS; c++) {
+        const unsigned long long m = __ballot(live && k == 0u && cls == c);
+        if (m != 0ull && (threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)m) - 1))
+            atomicAdd(group_counts + (tile / RT_ORDER_GROUP) * RT_COST_BINS + c, (uint32_t)__popcll(m));
     }
 }
 
@@ -2775,7 +2780,9 @@ int rt_render_frame_multi(RtScene* const* scenes, uint32_t n_scenes, const RtSet
     std::lock_guard<std::mutex> mg(multi_lock);
     // ---- context: streams, events, peer access; rebuilt when the list of replicas changes
     MultiContext* mc = s0->multi;
-    if (!mc || mc->scenes != std::vector<RtScene*>(scenes, scenes + n_scenes)) {
+    bool same = mc && mc->scenes == std::vector<RtScene*>(scenes, scenes + n_scenes);
+    for (uint32_t i = 0; same && i < n_scenes; i++) same = mc->dev[i].device == scenes[i]->device;      // (a replica destroyed and another created at its address)
+    if (!same) {
         if (mc) { mc->release(); delete mc; s0->multi = nullptr; }
         mc = new MultiContext();
         mc->scenes.assign(scenes, scenes + n_scenes);
