@@ -286,8 +286,13 @@ def oracle_legs(m, args, n_gpus, cpu_leg=True, cpu_seconds=None):
             traffic = None
     # the same fraction from the hardware counter of the committed PMC pass (executed lane-flops per ray x this run's ray rate)
     counter_frac = counter_flops_per_ray = None
-    pmc_key = PMC_WORKLOAD.get(m["workload"], m["workload"])
     cnt_path = os.path.join(ROOT, "profiles", "pmc_counters.json")
+    pmc_key = m["workload"]
+    try:              # a workload without counter passes of its own borrows those of the same scene at 64 spp
+        if pmc_key not in json.load(open(cnt_path)):
+            pmc_key = PMC_WORKLOAD.get(pmc_key, pmc_key)
+    except Exception:
+        pmc_key = PMC_WORKLOAD.get(pmc_key, pmc_key)
     if os.path.exists(cnt_path) and n_gpus == 1:
         try:
             c = json.load(open(cnt_path)).get(pmc_key)

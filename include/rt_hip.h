@@ -299,9 +299,6 @@ enum {
     RT_OPT_ROUND_UNITS = 3,
     /* circle of confusion (pixels, default 3) from which a tile is traced in rounds of one lens cell.  Schedule only. */
     RT_OPT_LENS_COC_PX = 4,
-    /* 0 / 1: the rays a wave starts together are of one kind - shadow rays light by light, then path rays; lanes of a
-     * later kind wait for a later burst.  Schedule only. */
-    RT_OPT_KIND_ORDER = 5,
     /* tests of RT_E_DEPTH: run the kernels with a traversal stack of this many entries (0 = what the trees
      * need) and clear the scene's sticky overflow error.  Synchronises the device. */
     RT_OPT_DEBUG_STACK_ENTRIES = 100,

@@ -52,7 +52,6 @@ pub const RT_OPT_LENS_SAMPLER: u32 = 1;
 pub const RT_OPT_FINE_SPLIT: u32 = 2;
 pub const RT_OPT_ROUND_UNITS: u32 = 3;
 pub const RT_OPT_LENS_COC_PX: u32 = 4;
-pub const RT_OPT_KIND_ORDER: u32 = 5;
 pub const RT_OPT_DEBUG_STACK_ENTRIES: u32 = 100;
 pub const RT_OPT_DEBUG_REBUILD_STACK_LIMIT: u32 = 101;
 

@@ -26,7 +26,6 @@ RT_DEVICE_HOST_ONLY = -1
 # rt_scene_set_option
 RT_OPT_LENS_SAMPLER, RT_OPT_FINE_SPLIT, RT_OPT_ROUND_UNITS, RT_OPT_LENS_COC_PX, RT_OPT_DEBUG_STACK_ENTRIES = 1, 2, 3, 4, 100
 RT_OPT_DEBUG_REBUILD_STACK_LIMIT = 101
-RT_OPT_KIND_ORDER = 5
 
 
 class RtV3(C.Structure):

@@ -736,7 +736,12 @@ render_kernel(const DevSceneView S, const RenderParams P) {
     // (or, with `tracing` false, has just finished and waits for its shading).
     enum { PATH = 0, SHADOW = 1, NEED_LIGHT = 2, NEED_PATH = 3, NEED_SAMPLE = 4, NEED_BLOCK = 5, FINISHED = 6 };
     int state = NEED_BLOCK;
-    bool tracing = false, held = false;      // held: a ray is waiting to start (RT_OPT_KIND_ORDER)
+    bool tracing = false;
+#ifdef RT_KIND_ORDER_EXPERIMENT
+    bool held = false;                       // a ray is waiting to start
+#else
+    constexpr bool held = false;
+#endif
     uint32_t pxy = 0, s = RT_NONE;           // pixel (x | y << 16) and sample index of the lane's current round (RT_NONE: no sample)
     // the wave's current block (wave-uniform): tile, unit, rounds started
     uint32_t blk_tile = 0, blk_unit = 0, round_next = 0, blk_lens = 0;
@@ -1093,10 +1098,11 @@ render_kernel(const DevSceneView S, const RenderParams P) {
         }
         if (!tracing && state != NEED_BLOCK && state != FINISHED) {
             // ================= start the traversal of the new ray ==========================
-            // RT_OPT_KIND_ORDER: the rays that start together are of one kind - the shadow rays towards the lowest-numbered light any lane has
+            // RT_KIND_ORDER_EXPERIMENT (`make kindorder`, RT_KIND_ORDER=1; measured neutral, and merely compiled in it costs weekend and Dreadnaught 1 %): the rays that start together are of one kind - the shadow rays towards the lowest-numbered light any lane has
             // waiting, path rays only when no lane has a shadow ray left; the other lanes are held back for a later burst (their order of
             // operations is unchanged: only the schedule moves, never a pixel).
             bool go = state == PATH || state == SHADOW;
+#ifdef RT_KIND_ORDER_EXPERIMENT
             if (go && P.kind_order) {
                 uint32_t first_light = 0xffu;
                 for (uint32_t k = 0; k < S.light_count; k++)
@@ -1104,6 +1110,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                 if (first_light != 0xffu) go = state == SHADOW && light_k == first_light;
                 held = !go;
             }
+#endif
             if (go) {
                 PH(PH_TRACE_INIT);
                 TM(TM_OTHER);
@@ -1766,7 +1773,7 @@ struct SceneOptions {
     int fine_split = -1;            // RT_OPT_FINE_SPLIT: -1 automatic, 0 whole segments, 1 single samples
     int round_units = 8;            // RT_OPT_ROUND_UNITS
     float lens_coc_px = 3.0f;       // RT_OPT_LENS_COC_PX (with 8 x 8 lens cells: mesh_demo 4K x 1024 spp 16 871 / 16 819 / 16 732 / 16 484 / 16 000 Mrays/s at 2 / 3 / 4 / 6 / 8 px, weekend within 0.6 %)
-    int kind_order = 0;             // RT_OPT_KIND_ORDER
+    int kind_order = 0;             // RT_KIND_ORDER=1 in the RT_KIND_ORDER_EXPERIMENT build
     uint32_t debug_stack_entries = 0;   // RT_OPT_DEBUG_STACK_ENTRIES: 0 = what the trees need
     uint32_t debug_rebuild_stack_limit = 0;   // RT_OPT_DEBUG_REBUILD_STACK_LIMIT: rt_scene_rebuild_tlas refuses trees that need more stack entries (0 = the LDS limit)
 };
@@ -2203,9 +2210,6 @@ int rt_scene_set_option(RtScene* scene, uint32_t option, double value) {
         case RT_OPT_ROUND_UNITS:
             if (value != 1.0 && value != 2.0 && value != 4.0 && value != 8.0) return set_error(RT_E_INVALID, "RT_OPT_ROUND_UNITS: 1, 2, 4 or 8");
             scene->opt.round_units = (int)value; return RT_OK;
-        case RT_OPT_KIND_ORDER:
-            if (value != 0.0 && value != 1.0) return set_error(RT_E_INVALID, "RT_OPT_KIND_ORDER: 0 or 1");
-            scene->opt.kind_order = (int)value; return RT_OK;
         case RT_OPT_LENS_COC_PX:
             if (!(value >= 0.0)) return set_error(RT_E_INVALID, "RT_OPT_LENS_COC_PX: a circle of confusion in pixels, >= 0");
             scene->opt.lens_coc_px = (float)value; return RT_OK;

@@ -269,7 +269,7 @@ class Scene:
 
     OPTIONS = {"lens_sampler": _ffi.RT_OPT_LENS_SAMPLER, "fine_split": _ffi.RT_OPT_FINE_SPLIT, "round_units": _ffi.RT_OPT_ROUND_UNITS,
                "lens_coc_px": _ffi.RT_OPT_LENS_COC_PX, "debug_stack_entries": _ffi.RT_OPT_DEBUG_STACK_ENTRIES,
-               "debug_rebuild_stack_limit": _ffi.RT_OPT_DEBUG_REBUILD_STACK_LIMIT, "kind_order": _ffi.RT_OPT_KIND_ORDER}
+               "debug_rebuild_stack_limit": _ffi.RT_OPT_DEBUG_REBUILD_STACK_LIMIT}
 
     def set_option(self, name, value):
         """rt_scene_set_option: "lens_sampler" 0 = the reference's independent lens draws / 1 = stratified (default);
