@@ -103,6 +103,8 @@ struct DevSceneView {
     float coc_rel_max;            // upper bound of a primary hit's circle of confusion, as a fraction of the image width (inf: unbounded)
     uint32_t rich_shading;        // some light is a lamp (cone), or some texture is not a plain colour / a checker
     uint32_t lds_nodes;           // the first lds_nodes node records are kept in LDS by the render kernel
+    uint32_t lds_ents;            // != 0 (then = entity_count): word 0 of every entity record (centre, radius) is kept in LDS behind the node cache - scenes
+                                  // of plain translated spheres only, where word 0 is all a leaf test reads (set by rt_scene_create when the block's LDS has the room)
     const DevNode* nodes;         // the top levels of the TLAS and of every BLAS first (breadth first), then the rest of each tree (depth first)
     const DevEntity* entities;    // TLAS leaf order
     const Word4* ent_box;         // per entity (TLAS leaf order) its own world box, 2 words: (lo.xyz, -) (hi.xyz, -); Entity::calculate_origin_aabb

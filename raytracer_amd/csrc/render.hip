@@ -706,7 +706,8 @@ enum { PH_NODE = 0, PH_TRI, PH_ENTITY, PH_SHADE, PH_SHADE_PATH_HIT, PH_SHADE_SHA
 // RICH: lamp lights, or textures other than colours and checkers (S.rich_shading);
 // DOF: some primary hit can be out of focus by more than the threshold of the lens-cell rounds (S.coc_rel_max x image
 //   width, decided per launch): without it the second round shape is compiled out (Dreadnaught +3 %).
-template <bool LOOSE, bool MESH, bool SPHERES, bool PLANES, bool XFORMS, bool RICH, bool DOF, bool MULTI = false>
+// ECACHE: a scene of plain translated spheres whose entity records fit into LDS beside the node cache (S.lds_ents): leaf tests read them there.
+template <bool LOOSE, bool MESH, bool SPHERES, bool PLANES, bool XFORMS, bool RICH, bool DOF, bool MULTI = false, bool ECACHE = false>
 __global__ void __launch_bounds__(RT_BLOCK, RT_WAVES_PER_SIMD)
 render_kernel(const DevSceneView S, const RenderParams P) {
     extern __shared__ uint32_t lds_stack[];
@@ -772,6 +773,14 @@ render_kernel(const DevSceneView S, const RenderParams P) {
         const float4 v = *reinterpret_cast<const float4*>(&S.nodes[i >> 2].w[i & 3u]);
         *reinterpret_cast<float4*>(node_cache + (i >> 2) * (RT_NODE_CACHE_STRIDE / 4u) + (i & 3u) * 4u) = v;
     }
+    // Sphere cache: in a scene of plain translated spheres a leaf test reads word 0 of the entity record and nothing else; with all of them in LDS
+    // the walk of such a scene issues no vector-memory read at all (the leaf pass was latency-bound: 183 SIMD cycles for ~75 of VALU work).
+    // An instantiation of its own (ECACHE): a run-time switch between LDS and memory in the leaf test cost scenes WITHOUT the cache 2.4 %.
+    static_assert(!ECACHE || (SPHERES && !MESH && !PLANES && !XFORMS && !LOOSE), "the sphere cache holds word 0 of the entity records only");
+    uint32_t* const ent_cache = node_cache + S.lds_nodes * (RT_NODE_CACHE_STRIDE / 4u);
+    if (ECACHE)
+        for (uint32_t i = threadIdx.x; i < S.lds_ents; i += RT_BLOCK)
+            *reinterpret_cast<float4*>(ent_cache + i * 4u) = *reinterpret_cast<const float4*>(&S.entities[i].w[0]);
     __syncthreads();
 
     for (;;) {
@@ -1261,7 +1270,11 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                             };
                             constexpr bool MESH_ONLY = MESH && !SPHERES && !PLANES;
                             if (MULTI && MESH_ONLY && !LOOSE && RT_OWN_BOX_PRETEST && misses_own_box()) continue;
-                            const Word4 e0 = ldw(ew), e1 = ldw(ew + 1);
+                            Word4 e0, e1;
+                            if (ECACHE) {      // (e1 is dead in this instantiation)
+                                const float4 v = *reinterpret_cast<const float4*>(ent_cache + ei * 4u);
+                                e0.f[0] = v.x; e0.f[1] = v.y; e0.f[2] = v.z; e0.f[3] = v.w; e1 = e0;
+                            } else { e0 = ldw(ew); e1 = ldw(ew + 1); }
                             const uint32_t kind = e1.u[0] & 0xff;
                             if (MULTI && MESH && !MESH_ONLY && !LOOSE && RT_OWN_BOX_PRETEST && kind == RT_HITABLE_MESH && misses_own_box()) continue;
                             F3 eo = wo, ed = wd;
@@ -2076,9 +2089,14 @@ int enqueue_accumulate(RtScene* scene, Workspace& ws, const RtSettings* st, cons
                         (dof ? 32 : 0);
             if ((which & 7) == 0) which |= 2;                                        // (an empty scene: any instantiation will do)
             static const bool show_traits = getenv("RT_DEBUG_TRAITS") != nullptr;      // diagnostics: which instantiation a scene runs
-            if (show_traits) fprintf(stderr, "traits: which=%d loose=%u any_hit=%u lds_nodes=%u\n", which, v.loose_boxes, v.shadow_any_hit, v.lds_nodes);
+            if (show_traits) fprintf(stderr, "traits: which=%d loose=%u any_hit=%u lds_nodes=%u lds_ents=%u stack=%u lds_bytes=%zu\n", which, v.loose_boxes, v.shadow_any_hit, v.lds_nodes, v.lds_ents, v.stack_entries, scene->lds_bytes);
             const bool multi = v.mesh_entities && v.entity_count > 1u;
-            const Kernel kernel = v.loose_boxes ? render_kernel<true, true, true, true, true, true, true> : (multi ? kernels_multi[which] : kernels[which]);
+            // plain translated spheres with their records in LDS (S.lds_ents, size_sphere_cache): index bits 1 rich shading, 2 depth of field
+            static const Kernel kernels_ecache[4] = {render_kernel<false, false, true, false, false, false, false, false, true>, render_kernel<false, false, true, false, false, true, false, false, true>,
+                                                     render_kernel<false, false, true, false, false, false, true, false, true>,  render_kernel<false, false, true, false, false, true, true, false, true>};
+            const bool ecache = v.lds_ents != 0u && !v.loose_boxes && (which & 15) == 2;
+            const Kernel kernel = v.loose_boxes ? render_kernel<true, true, true, true, true, true, true> : ecache ? kernels_ecache[(which >> 4) & 3] :
+                                  (multi ? kernels_multi[which] : kernels[which]);
             hipLaunchKernelGGL(kernel, dim3((uint32_t)blocks), dim3(RT_BLOCK), scene->lds_bytes, stream, view, P);
         }
         HIP_TRY(hipGetLastError());
@@ -2116,6 +2134,17 @@ int enqueue_accumulate(RtScene* scene, Workspace& ws, const RtSettings* st, cons
         P.progress_base += (uint32_t)((uint64_t)(pix_slots / 64) * P.unit_count);
     }
     return RT_OK;
+}
+
+// The sphere cache of the render kernel (DevSceneView::lds_ents): all or nothing - every entity's word 0, 16 bytes each, behind the node cache, when the
+// scene is plain translated spheres only and a block's share of the LDS (four blocks per CU) still has the room.  Returns the bytes it takes.
+size_t size_sphere_cache(DevSceneView& v, size_t lds_bytes_so_far) {
+    static const bool off = getenv("RT_NO_SPHERE_CACHE") != nullptr;      // (A/B measurements)
+    const size_t block_budget = (size_t)160 * 1024 * RT_BLOCK / (256 * RT_WAVES_PER_SIMD);
+    const bool plain_spheres = v.sphere_entities && !v.plane_entities && !v.mesh_entities && !v.general_xforms && !v.loose_boxes;
+    const size_t bytes = (size_t)v.entity_count * 16u;
+    v.lds_ents = (!off && plain_spheres && lds_bytes_so_far + bytes <= block_budget) ? v.entity_count : 0u;
+    return v.lds_ents ? bytes : 0u;
 }
 
 }  // namespace
@@ -2178,6 +2207,7 @@ RtScene* rt_scene_create(const RtSceneDesc* desc, int device) {
     s->lds_bytes = ((size_t)s->view.stack_entries + (s->view.mesh_entities ? 3 : 0)) * RT_BLOCK * sizeof(uint32_t);      // + 3 rows: parked world-space 1/d
     s->stack_lds_bytes = s->lds_bytes;
     s->lds_bytes += (size_t)s->view.lds_nodes * RT_NODE_CACHE_STRIDE;      // the node cache (sized by scene_build.cpp to fit four blocks per CU)
+    s->lds_bytes += size_sphere_cache(s->view, s->lds_bytes);
     if (s->stack_lds_bytes > 64 * 1024) { set_error(RT_E_DEPTH, "BVH too deep for the LDS traversal stack (more than 64 levels)"); return fail(); }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { set_error(RT_E_HIP, "hipGetDeviceProperties failed"); return fail(); }
@@ -2542,6 +2572,7 @@ int rt_scene_rebuild_tlas(RtScene* scene, const RtV3* translations, uint64_t tra
     scene->view.lds_nodes = (uint32_t)std::min<size_t>(scene->lds_nodes_built, room);
     scene->stack_lds_bytes = stack_bytes;
     scene->lds_bytes = stack_bytes + (size_t)scene->view.lds_nodes * RT_NODE_CACHE_STRIDE;
+    scene->lds_bytes += size_sphere_cache(scene->view, scene->lds_bytes);
     scene->info.tlas_depth = height0;
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_kernel<true, true, true, true, true, true, true>, RT_BLOCK, scene->lds_bytes) == hipSuccess && per_cu >= 1) {
@@ -2722,6 +2753,7 @@ int rt_scene_rebuild_blas(RtScene* scene, uint32_t mesh_index, const RtMeshTri* 
     scene->view.lds_nodes = (uint32_t)std::min<size_t>(scene->lds_nodes_built, room);
     scene->stack_lds_bytes = stack_bytes;
     scene->lds_bytes = stack_bytes + (size_t)scene->view.lds_nodes * RT_NODE_CACHE_STRIDE;
+    scene->lds_bytes += size_sphere_cache(scene->view, scene->lds_bytes);
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_kernel<true, true, true, true, true, true, true>, RT_BLOCK, scene->lds_bytes) == hipSuccess && per_cu >= 1) {
         hipDeviceProp_t prop;

@@ -601,7 +601,9 @@ int build_flat_scene(const RtSceneDesc* d, FlatScene& out, std::string& err) {
     }
     // traversal stack: one deferred sibling per inner level of the TLAS, one
     // TLAS-leaf continuation, one per inner level of the deepest BLAS, + margin
-    v.stack_entries = tlas_walk_depth + 1 + blas_walk_depth + 2;
+    // (a scene without meshes needs exactly tlas_walk_depth entries - Emitter::depth is the maximum of inner records on a path, each defers one sibling at
+    //  most - and gets one to spare: the LDS a block saves holds the sphere cache of the headline scene, render.hip size_sphere_cache)
+    v.stack_entries = d->mesh_object_count ? tlas_walk_depth + 1 + blas_walk_depth + 2 : tlas_walk_depth + 1;
 
     // ---- node records: the top levels of every tree first (the LDS node cache), then the rest --------
     // LDS of a render block = its lanes' traversal stacks + the cache; four blocks share a CU's 160 KB.
