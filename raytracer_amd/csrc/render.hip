@@ -1289,10 +1289,11 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                                 const float discriminant = qb * qb - qa * qc;
                                 if (discriminant > 0.0f) {
                                     const float sq = sqrtf(discriminant);
-                                    const float t0 = (-qb - sq) / qa, t1 = (-qb + sq) / qa;
-                                    const bool in0 = t_min < t0 && t0 < t_max, in1 = t_min < t1 && t1 < t_max;
-                                    hit = in0 || in1;
-                                    t = (in0 && in1) ? fminf(t0, t1) : (in0 ? t0 : t1);
+                                    // the far root only where the near one is out of range: qa = |d|^2 >= 0 and sq >= 0 give t0 <= t1 (division is monotonic), so an
+                                    // accepted t0 IS min(t0, t1) whether or not t1 is in range (sphere.rs:7-16 evaluates both; same result, one division less)
+                                    const float t0 = (-qb - sq) / qa;
+                                    hit = t_min < t0 && t0 < t_max; t = t0;
+                                    if (!hit) { const float t1 = (-qb + sq) / qa; hit = t_min < t1 && t1 < t_max; t = t1; }      // (weekend +0.5 %)
                                 }
                             } else if (PLANES && (!MESH || kind == RT_HITABLE_PLANE)) {
                                 // intersect_plane + Plane::hit, plane.rs:4-17, 59-70
