@@ -20,6 +20,7 @@ for p in $PASSES; do
     tcc1) run_pass tcc1 FETCH_SIZE TCC_HIT_sum || exit 1;;
     tcc2) run_pass tcc2 WRITE_SIZE TCC_MISS_sum TCC_REQ_sum || exit 1;;
     grbm) run_pass grbm GRBM_GUI_ACTIVE GRBM_COUNT || exit 1;;
+    sqc) run_pass sqc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE || exit 1;;
     ta) run_pass ta TA_BUSY_avr TA_ADDR_STALL_CYCLES_sum TCP_TCP_TA_ADDR_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TAGRAM0_REQ_sum TCP_GATE_EN1_sum || exit 1;;
     ta2) run_pass ta2 TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_TD_TCP_STALL_CYCLES_sum TCP_GATE_EN2_sum || exit 1;;
   esac
