@@ -101,6 +101,8 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default=HEADLINE, choices=sorted(WORKLOADS))
     ap.add_argument("--mode", default="tiles", choices=["tiles", "spp"], help="N>1: tile partition + gather, or spp split + accumulator sum")
+    ap.add_argument("--partition", default="columns", choices=["columns", "strips"],
+                    help="tile mode, N>1: 8-pixel tile columns (every rank holds a share of every image region) or 8-row strips, dealt round-robin")
     ap.add_argument("--reduce", default="ordered", choices=["ordered", "allreduce"],
                     help="--mode spp: gather + sum in rank order on rank 0 (deterministic), or one RCCL all-reduce")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle legs (roofline statistics and CPU baseline)")
@@ -142,7 +144,7 @@ def measure(workload, args, ctx, mode=None, reduce=None, steps=None, warmup=None
     if warmup is not None: args.warmup = warmup
     import torch
     from raytracer_amd import CameraConfiguration, RenderChunk, RenderSettings, Scene, SceneBuilder, resolve_device
-    from raytracer_amd.dist import InterleavedCompositor, reduce_accumulators, sample_range_of_rank
+    from raytracer_amd.dist import ColumnCompositor, InterleavedCompositor, reduce_accumulators, sample_range_of_rank
     dist, rank, n_gpus, dev, device = ctx["dist"], ctx["rank"], ctx["n_gpus"], ctx["dev"], ctx["device"]
 
     scene_name, W, H, spp, depth, lens, params = WORKLOADS[workload]
@@ -156,9 +158,10 @@ def measure(workload, args, ctx, mode=None, reduce=None, steps=None, warmup=None
     stream = torch.cuda.current_stream().cuda_stream
     whole = RenderChunk(0, 0, W, H)
     if args.mode == "tiles":
-        comp = InterleavedCompositor(W, H, rank, n_gpus, dev, strip_height=8)
+        strips = getattr(args, "partition", "columns") == "strips"
+        comp = InterleavedCompositor(W, H, rank, n_gpus, dev, strip_height=8) if strips else ColumnCompositor(W, H, rank, n_gpus, dev)
         parallelism = ("single GPU" if n_gpus == 1 else
-                       f"8-row strips dealt round-robin over {n_gpus} GPUs, one launch per GPU, RCCL gather to rank 0")
+                       (f"8-row strips" if strips else "8-pixel tile columns") + f" dealt round-robin over {n_gpus} GPUs, one launch per GPU, RCCL gather to rank 0")
     else:
         s_first, s_count = sample_range_of_rank(spp, rank, n_gpus)
         acc = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
@@ -170,9 +173,11 @@ def measure(workload, args, ctx, mode=None, reduce=None, steps=None, warmup=None
         if args.mode == "tiles":
             if n_gpus == 1:
                 scene.render_chunk_device(settings, whole, SEED, comp.packed.data_ptr(), None, W, 0, 0, counters.data_ptr(), stream)
-            else:           # all of this rank's strips in one launch, straight into the send buffer
-                scene.render_strips_device(settings, comp.strip_height, rank, n_gpus, SEED, comp.packed.data_ptr(), None,
-                                           counters.data_ptr(), stream)
+            else:           # all of this rank's tile columns (or strips) in one launch, straight into the send buffer
+                if strips:
+                    scene.render_strips_device(settings, comp.strip_height, rank, n_gpus, SEED, comp.packed.data_ptr(), None, counters.data_ptr(), stream)
+                elif comp.my_width:
+                    scene.render_tile_columns_device(settings, rank, n_gpus, SEED, comp.packed.data_ptr(), None, counters.data_ptr(), stream)
                 comp.composite()
         else:
             acc.zero_()

@@ -378,6 +378,21 @@ int rt_render_strips_device(RtScene* scene, const RtSettings* settings,
 /* Rows owned by (strip_first, strip_period) in an image of `height` rows; < 0 on bad arguments. */
 int rt_strip_rows(uint32_t height, uint32_t strip_height, uint32_t strip_first, uint32_t strip_period);
 
+/* The finer tile partition (same role as rt_render_strips_device: the share of one of N GPUs of the reference's chunk
+ * queue, src/render.rs:186-224, 63-78; create_render_chunks(size,[n,1]) cut 8 pixels wide and dealt round-robin): this
+ * call renders, in ONE launch, the 8-pixel-wide tile columns col_first, col_first + col_period, ... over the whole height
+ * of the frame.  Every rank then holds a share of every region of the image, where 8-row strips cut a glass object or a
+ * dense mesh unevenly (the slowest of 8 ranks decides the frame time).  Outputs (device pointers, nullable) are PACKED:
+ * settings.height rows of rt_tile_columns_width() pixels, the owned columns side by side (the frame's last tile column may
+ * be narrower than 8).  Pixels are identical to those of rt_render_chunk for the same image positions. */
+int rt_render_tile_columns_device(RtScene* scene, const RtSettings* settings,
+                                  uint32_t col_first, uint32_t col_period,
+                                  uint64_t seed, void* rgb_dev, void* rgba_dev,
+                                  void* counters_dev, void* stream);
+/* Packed width in pixels of the tile columns owned by (col_first, col_period) in a frame `width` pixels wide
+ * (0: none); < 0 on bad arguments. */
+int rt_tile_columns_width(uint32_t width, uint32_t col_first, uint32_t col_period);
+
 /* spp-split rendering (partitioning 2): adds the SUM of the
  * per-sample clamped colours (implementation.rs:635,656) of samples
  * [sample_first, sample_first+sample_count) to accum_dev (float3 per pixel,
@@ -395,10 +410,11 @@ int rt_accumulate_chunk_device(RtScene* scene, const RtSettings* settings,
  * device (rt_scene_create(desc, device); two replicas may also share a device).  One host thread per replica enqueues
  * that replica's share on a stream of its own; the call returns when the frame is complete in GPU 0's memory
  * (GPU 0 = scenes[0]'s device; rgb_dev0 / rgba_dev0 are device pointers THERE, width * height pixels, either nullable).
- *   RT_MULTI_TILES: 8-row strips dealt round-robin (replica i owns strips i, i + n, ...), every replica renders all its
- *                   strips in one launch (rt_render_strips_device) and writes them straight into GPU 0's frame over its
- *                   own xGMI link (peer access), or - where peer access is refused - packs them and copies strip by
- *                   strip (hipMemcpyPeerAsync).  The frame is that of ONE rt_render_chunk_device call, bit for bit.
+ *   RT_MULTI_TILES: 8-pixel tile columns dealt round-robin (replica i owns columns i, i + n, ...), every replica renders
+ *                   all its columns in one launch (rt_render_tile_columns_device) and writes them straight into GPU 0's
+ *                   frame over its own xGMI link (peer access), or - where peer access is refused - packs them, copies the
+ *                   packed image over (hipMemcpyPeerAsync) and GPU 0 puts the columns in place.  The frame is that of ONE
+ *                   rt_render_chunk_device call, bit for bit.
  *   RT_MULTI_SPP  : every replica renders the whole frame for its range of whole sample segments into an accumulator
  *                   (rt_accumulate_chunk_device); the accumulators are copied to GPU 0 and added there IN REPLICA ORDER,
  *                   then resolved (rt_resolve_device).  Equal to the one-call frame up to the association of the final

@@ -277,6 +277,8 @@ extern "C" {
     pub fn rt_noalloc_max_pixels() -> u64;
     pub fn rt_render_strips_device(scene: *mut RtScene, settings: *const RtSettings, strip_height: u32, strip_first: u32, strip_period: u32, seed: u64, rgb_dev: *mut c_void, rgba_dev: *mut c_void, counters_dev: *mut c_void, stream: *mut c_void) -> c_int;
     pub fn rt_strip_rows(height: u32, strip_height: u32, strip_first: u32, strip_period: u32) -> c_int;
+    pub fn rt_render_tile_columns_device(scene: *mut RtScene, settings: *const RtSettings, col_first: u32, col_period: u32, seed: u64, rgb_dev: *mut c_void, rgba_dev: *mut c_void, counters_dev: *mut c_void, stream: *mut c_void) -> c_int;
+    pub fn rt_tile_columns_width(width: u32, col_first: u32, col_period: u32) -> c_int;
     pub fn rt_accumulate_chunk_device(scene: *mut RtScene, settings: *const RtSettings, chunk: *const RtRenderChunk, seed: u64, sample_first: u32, sample_count: u32, accum_dev: *mut c_void, counters_dev: *mut c_void, stream: *mut c_void) -> c_int;
     pub fn rt_render_frame_multi(scenes: *const *mut RtScene, n_scenes: u32, settings: *const RtSettings, mode: u32, seed: u64, rgb_dev0: *mut c_void, rgba_dev0: *mut c_void, counters: *mut RtRayCounters) -> c_int;
     pub fn rt_render_frame_multi_host(scenes: *const *mut RtScene, n_scenes: u32, settings: *const RtSettings, mode: u32, seed: u64, rgb_out: *mut f32, rgba_out: *mut u8, counters: *mut RtRayCounters) -> c_int;

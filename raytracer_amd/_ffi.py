@@ -168,6 +168,9 @@ HIP_PROTOTYPES = {
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rt_sample_segment": (C.c_uint32, []),
     "rt_strip_rows": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "rt_render_tile_columns_device": (C.c_int, [C.c_void_p, _P(RtSettings), C.c_uint32, C.c_uint32, C.c_uint64,
+                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rt_tile_columns_width": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32]),
     "rt_accumulate_chunk_device": (C.c_int, [C.c_void_p, _P(RtSettings), _P(RtRenderChunk), C.c_uint64, C.c_uint32,
                                              C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rt_resolve_device": (C.c_int, [C.c_int, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -638,6 +638,7 @@ struct RenderParams {
     unsigned long long* phase_stats;                // diagnostics build only: [phase][lane-iterations, wave-iterations]
 #endif
     uint32_t strip_h, strip_period_rows, strip_first_row;   // strip_h != 0: local row y -> image row (interleaved strips)
+    uint32_t col_n, col_r;                          // col_n != 0: the chunk is the packed tile columns col_r, col_r + col_n, ... of the frame (local tile column j -> image tile column j * col_n + col_r)
 };
 
 // cast_rays_into_scene :645-646: the same two values for every sample of a pixel
@@ -746,7 +747,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
     uint32_t pxy = 0, s = RT_NONE;           // pixel (x | y << 16) and sample index of the lane's current round (RT_NONE: no sample)
     // the wave's current block (wave-uniform): tile, unit, rounds started
     uint32_t blk_tile = 0, blk_unit = 0, round_next = 0, blk_lens = 0;
-    uint32_t blk_xy0 = 0, blk_py0 = 0;          // the tile's first pixel: chunk-local x | y << 16, and its image row
+    uint32_t blk_xy0 = 0, blk_py0 = 0, blk_px0 = 0;   // the tile's first pixel: chunk-local x | y << 16, its image row and its image column
     F3 sample_col = f3(0, 0, 0);
     Pending pend[RT_PENDING_MAX]; uint32_t npend = 0;
     F3 ro = f3(0, 0, 0), rd = f3(0, 0, 1), rw = f3(0, 0, 0); uint32_t rlimit = 0, rnode = 0;   // current path ray
@@ -832,6 +833,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                     {
                         const uint32_t x0 = (blk_tile % P.tiles_x) * 8u, y0 = (blk_tile / P.tiles_x) * 8u;
                         blk_xy0 = x0 | (y0 << 16);
+                        blk_px0 = P.col_n ? ((x0 >> 3) * P.col_n + P.col_r) * 8u : P.left + x0;      // (dealt tile columns: rt_render_tile_columns_device)
                         // (strips are whole rows of tiles, so the 8 rows of a tile are consecutive image rows)
                         blk_py0 = P.strip_h ? P.strip_first_row + (y0 / P.strip_h) * P.strip_period_rows + (y0 % P.strip_h) : P.top + y0;
                     }
@@ -1067,7 +1069,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                 s = (x0 + x < P.cw && y0 + y < P.ch && s_ok) ? s_mine : RT_NONE;      // lanes off the chunk's edge sit the round out
                 if (s != RT_NONE) {
                     PH(PH_STAGE_C);
-                    const uint32_t px = P.left + x0 + x, py = blk_py0 + y;
+                    const uint32_t px = blk_px0 + x, py = blk_py0 + y;
                     pxy = px | (py << 16);
                     float pu, pv; pixel_uv(P, px, py, pu, pv);
                     float lx = 0.0f, ly = 0.0f;
@@ -1416,18 +1418,20 @@ __device__ __forceinline__ uint8_t f32_as_u8(float f) {      // Rust `as u8`: tr
 
 // col / spp (implementation.rs:659) and v3_to_rgba (src/rgba.rs:6-12).
 // Source: acc image (pitch src_pitch, origin sx,sy); destination images (pitch dst_pitch, origin dx,dy).
-// strip_h != 0: the source rows are one rank's packed strips and go to their image rows (strip k of the rank = rows first_row + k * period_rows ...):
+// strip_h != 0: the source rows are one rank's packed strips and go to their image rows (strip k of the rank = rows first_row + k * period_rows ...);
+// col_n != 0: the source columns are one rank's packed tile columns (8 pixels wide) and go to image tile columns col_r, col_r + col_n, ...:
 // the destination may then be the frame on ANOTHER device (rt_render_frame_multi writes each GPU's strips straight into GPU 0's frame over xGMI).
 __global__ void finish_kernel(const float* acc, uint32_t src_pitch, uint32_t sx, uint32_t sy, uint32_t cw, uint32_t npix, float spp,
                               float* rgb, uint8_t* rgba, uint32_t dst_pitch, uint32_t dx, uint32_t dy,
-                              uint32_t strip_h = 0u, uint32_t period_rows = 0u, uint32_t first_row = 0u) {
+                              uint32_t strip_h = 0u, uint32_t period_rows = 0u, uint32_t first_row = 0u, uint32_t col_n = 0u, uint32_t col_r = 0u) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= npix) return;
     const uint32_t x = i % cw, y = i / cw;
     const float* a = acc + ((uint64_t)(sy + y) * src_pitch + sx + x) * 3;
     const float r = a[0] / spp, g = a[1] / spp, b = a[2] / spp;
     const uint32_t row = strip_h ? first_row + (y / strip_h) * period_rows + (y % strip_h) : dy + y;
-    const uint64_t o = (uint64_t)row * dst_pitch + dx + x;
+    const uint32_t col = col_n ? ((x >> 3) * col_n + col_r) * 8u + (x & 7u) : dx + x;      // col_n != 0: packed tile columns go to their image columns
+    const uint64_t o = (uint64_t)row * dst_pitch + col;
     if (rgb) { rgb[o * 3] = r; rgb[o * 3 + 1] = g; rgb[o * 3 + 2] = b; }
     if (rgba) { rgba[o * 4] = f32_as_u8(255.0f * r); rgba[o * 4 + 1] = f32_as_u8(255.0f * g); rgba[o * 4 + 2] = f32_as_u8(255.0f * b); rgba[o * 4 + 3] = 255; }
 }
@@ -1456,7 +1460,7 @@ classify_kernel(const DevSceneView S, const RenderParams P, uint32_t n_tiles, ui
     uint32_t cls = 3u;
     float coc = 0.0f, hits = 0.0f;
     if (live && x < P.cw && y < P.ch) {
-        const uint32_t px = P.left + x;
+        const uint32_t px = P.col_n ? ((x >> 3) * P.col_n + P.col_r) * 8u + (x & 7u) : P.left + x;
         const uint32_t py = P.strip_h ? P.strip_first_row + (y / P.strip_h) * P.strip_period_rows + (y % P.strip_h) : P.top + y;
         float pu, pv; F3 o, d;
         pixel_uv(P, px, py, pu, pv);
@@ -1758,7 +1762,7 @@ struct MultiContext {
         hipEvent_t done = nullptr;
         bool direct = false;                  // this device can write GPU 0's memory (the same device, or peer access enabled)
         DeviceBuffer counters, packed_rgb, packed_rgba, accum;
-        DeviceBuffer staging;                 // on GPU 0: this device's accumulator, copied over (spp mode)
+        DeviceBuffer staging, staging_rgba;   // on GPU 0: this device's accumulator (spp mode) / packed tile columns (tile mode without peer access), copied over
         RtRayCounters host_counters{};
         int rc = RT_OK; std::string error;
     };
@@ -1772,7 +1776,7 @@ struct MultiContext {
             if (d.done) (void)hipEventDestroy(d.done);
             d.counters.release(); d.packed_rgb.release(); d.packed_rgba.release(); d.accum.release();
         }
-        if (!dev.empty()) { (void)hipSetDevice(dev[0].device); for (auto& d : dev) d.staging.release(); total.release(); }
+        if (!dev.empty()) { (void)hipSetDevice(dev[0].device); for (auto& d : dev) { d.staging.release(); d.staging_rgba.release(); } total.release(); }
         dev.clear(); scenes.clear();
     }
 };
@@ -1949,7 +1953,7 @@ size_t order_buffer_bytes(size_t n_tiles) { return ((n_tiles + RT_ORDER_GROUP - 
 
 // Enqueue: accumulate the sum of clamped samples [first, first+count) of the chunk
 // into `acc` (float3 image with pitch acc_pitch, chunk origin at acc_x/acc_y).
-struct Interleave { uint32_t strip_h = 0, period_rows = 0, first_row = 0; };
+struct Interleave { uint32_t strip_h = 0, period_rows = 0, first_row = 0, col_n = 0, col_r = 0; };
 
 int enqueue_accumulate(RtScene* scene, Workspace& ws, const RtSettings* st, const RtRenderChunk* ch, uint64_t seed, uint32_t sample_first,
                        uint32_t sample_count, float* acc, uint32_t acc_pitch, uint32_t acc_x, uint32_t acc_y, bool init_zero,
@@ -1996,7 +2000,7 @@ int enqueue_accumulate(RtScene* scene, Workspace& ws, const RtSettings* st, cons
     P.tiles_x = tiles_x; P.pix_slots = pix_slots; P.unit_len = unit_len;
     P.partial = (float*)ws.partial.p;
     P.counters = counters_dev;
-    P.strip_h = il.strip_h; P.strip_period_rows = il.period_rows; P.strip_first_row = il.first_row;
+    P.strip_h = il.strip_h; P.strip_period_rows = il.period_rows; P.strip_first_row = il.first_row; P.col_n = il.col_n; P.col_r = il.col_r;
     P.lens_coc_px = opt.lens_coc_px;      // circle of confusion in pixels from which a tile runs lens-cell rounds (a huge value turns them off)
     P.lens_stratify = opt.lens_stratify ? 1u : 0u;
     P.kind_order = opt.kind_order ? 1u : 0u;
@@ -2628,6 +2632,52 @@ int rt_render_strips_device(RtScene* scene, const RtSettings* st, uint32_t strip
     return render_strips_on(scene, st, strip_height, strip_first, strip_period, seed, rgb_dev, rgba_dev, false, counters_dev, (hipStream_t)stream);
 }
 
+// ---- dealt tile columns: the finer partition of a frame over N GPUs ---------------------------------------------------------------------
+// Rank r of N owns the 8-pixel-wide tile columns r, r + N, r + 2N, ... over the whole height of the frame: every rank gets a share of every
+// region of the image, where 8-row strips cut a glass object unevenly (per-rank kernel times of the 8-rank split, emulated on one GPU:
+// DESIGN.md section 6).  Packed layout: `height` rows of rt_tile_columns_width() pixels, tile column j of the rank at packed columns 8j..8j+7.
+int rt_tile_columns_width(uint32_t width, uint32_t col_first, uint32_t col_period) {
+    if (col_period == 0 || col_first >= col_period) return RT_E_INVALID;
+    const uint64_t tiles_x = ((uint64_t)width + 7) / 8;
+    if (col_first >= tiles_x) return 0;
+    const uint64_t cols = (tiles_x - col_first + col_period - 1) / col_period;
+    uint64_t w = cols * 8;
+    if (col_first + (cols - 1) * col_period == tiles_x - 1) w -= tiles_x * 8 - width;      // the frame's last tile column may be narrower
+    return (int)w;
+}
+
+// Body of rt_render_tile_columns_device.  interleave_dst: write every column to its place in a full frame of pitch st->width (which may live on
+// another device with peer access) instead of packing the columns.
+static int render_columns_on(RtScene* scene, const RtSettings* st, uint32_t col_first, uint32_t col_period, uint64_t seed, void* rgb_dev, void* rgba_dev,
+                             bool interleave_dst, void* counters_dev, hipStream_t sm) {
+    if (!st) return set_error(RT_E_INVALID, "null argument");
+    const int pw = rt_tile_columns_width(st->width, col_first, col_period);
+    if (pw < 0) return set_error(RT_E_INVALID, "rt_render_tile_columns_device: col_period must be > 0, col_first < col_period");
+    if (pw == 0) return RT_OK;                           // this rank owns no column of so narrow an image
+    RtRenderChunk local{0, 0, (uint32_t)pw, st->height};   // the packed columns
+    int rc = validate_call(scene, st, &local);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> g(scene->lock);
+    HIP_TRY(hipSetDevice(scene->device));
+    const uint32_t npix = local.width * local.height;
+    Workspace& ws = scene->shared;
+    if ((rc = ws.accum.ensure((size_t)npix * 12))) return rc;
+    Interleave il; il.col_n = col_period; il.col_r = col_first;
+    rc = enqueue_accumulate(scene, ws, st, &local, seed, 0, st->samples_per_pixel, (float*)ws.accum.p, local.width, 0, 0, true,
+                            (unsigned long long*)counters_dev, sm, il);
+    if (rc) return rc;
+    hipLaunchKernelGGL(finish_kernel, dim3((npix + 255) / 256), dim3(256), 0, sm, (const float*)ws.accum.p, local.width, 0u, 0u, local.width, npix,
+                       (float)st->samples_per_pixel, (float*)rgb_dev, (uint8_t*)rgba_dev, interleave_dst ? st->width : local.width, 0u, 0u,
+                       0u, 0u, 0u, interleave_dst ? il.col_n : 0u, il.col_r);
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+int rt_render_tile_columns_device(RtScene* scene, const RtSettings* st, uint32_t col_first, uint32_t col_period, uint64_t seed, void* rgb_dev, void* rgba_dev,
+                                  void* counters_dev, void* stream) {
+    return render_columns_on(scene, st, col_first, col_period, seed, rgb_dev, rgba_dev, false, counters_dev, (hipStream_t)stream);
+}
+
 int rt_accumulate_chunk_device(RtScene* scene, const RtSettings* st, const RtRenderChunk* ch, uint64_t seed, uint32_t sample_first,
                                uint32_t sample_count, void* accum_dev, void* counters_dev, void* stream) {
     int rc = validate_call(scene, st, ch);
@@ -2789,6 +2839,17 @@ int rt_scene_progress(const RtScene* scene, uint64_t* blocks_done, uint64_t* blo
 
 // ---- one frame on N GPUs, composited on the first (src/render.rs:186-224 across devices) -------------------------------------------
 // total[p] = acc_0[p] + acc_1[p] + ... in rank order (the deterministic sum of raytracer_amd/dist.py: reduce_accumulators "ordered")
+// one rank's packed tile columns (copied to this GPU) to their places in the frame: the composite where a replica cannot write GPU 0's memory itself
+__global__ void unpack_columns_kernel(const float* src_rgb, const uint8_t* src_rgba, uint32_t pw, uint32_t npix, uint32_t col_n, uint32_t col_r,
+                                      float* rgb, uint8_t* rgba, uint32_t dst_pitch) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    const uint32_t x = i % pw, y = i / pw;
+    const uint64_t o = (uint64_t)y * dst_pitch + ((x >> 3) * col_n + col_r) * 8u + (x & 7u);
+    if (rgb) { rgb[o * 3] = src_rgb[(uint64_t)i * 3]; rgb[o * 3 + 1] = src_rgb[(uint64_t)i * 3 + 1]; rgb[o * 3 + 2] = src_rgb[(uint64_t)i * 3 + 2]; }
+    if (rgba) reinterpret_cast<uint32_t*>(rgba)[o] = reinterpret_cast<const uint32_t*>(src_rgba)[i];
+}
+
 __global__ void sum_ranks_kernel(float* total, const float* const* parts, uint32_t n_parts, uint64_t n_floats) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_floats) return;
@@ -2846,7 +2907,6 @@ int rt_render_frame_multi(RtScene* const* scenes, uint32_t n_scenes, const RtSet
         s0->multi = mc;
     }
     // ---- per device: enqueue its share on its own stream, from its own host thread (the reference's worker threads, one per GPU)
-    const uint32_t strip_h = 8u;
     auto work = [&](uint32_t i) {
         MultiContext::PerDevice& d = mc->dev[i];
         RtScene* sc = scenes[i];
@@ -2858,26 +2918,20 @@ int rt_render_frame_multi(RtScene* const* scenes, uint32_t n_scenes, const RtSet
         if ((rc = d.counters.ensure(sizeof(RtRayCounters)))) return fail(rc);
         if (!hip(hipMemsetAsync(d.counters.p, 0, sizeof(RtRayCounters), d.stream), "hipMemsetAsync")) return;
         if (mode == RT_MULTI_TILES) {
-            const int rows = rt_strip_rows(st->height, strip_h, i, n_scenes);
-            if (rows > 0) {
+            const int pw = rt_tile_columns_width(st->width, i, n_scenes);
+            if (pw > 0) {
                 if (d.direct) {
-                    // every strip straight to its rows of GPU 0's frame (over this GPU's own xGMI link when it is another device)
-                    if ((rc = render_strips_on(sc, st, strip_h, i, n_scenes, seed, rgb_dev0, rgba_dev0, true, d.counters.p, d.stream))) return fail(rc);
+                    // every tile column straight to its place in GPU 0's frame (over this GPU's own xGMI link when it is another device)
+                    if ((rc = render_columns_on(sc, st, i, n_scenes, seed, rgb_dev0, rgba_dev0, true, d.counters.p, d.stream))) return fail(rc);
                 } else {
-                    // no peer access: packed strips here, then one copy per strip and output
-                    if (rgb_dev0 && (rc = d.packed_rgb.ensure((size_t)rows * st->width * 12))) return fail(rc);
-                    if (rgba_dev0 && (rc = d.packed_rgba.ensure((size_t)rows * st->width * 4))) return fail(rc);
-                    if ((rc = render_strips_on(sc, st, strip_h, i, n_scenes, seed, rgb_dev0 ? d.packed_rgb.p : nullptr, rgba_dev0 ? d.packed_rgba.p : nullptr, false, d.counters.p, d.stream)))
+                    // no peer access: packed columns here, one copy per output to GPU 0 (staged through the host by the runtime), unpacked there below
+                    const size_t np = (size_t)pw * st->height;
+                    if (rgb_dev0 && (rc = d.packed_rgb.ensure(np * 12))) return fail(rc);
+                    if (rgba_dev0 && (rc = d.packed_rgba.ensure(np * 4))) return fail(rc);
+                    if ((rc = render_columns_on(sc, st, i, n_scenes, seed, rgb_dev0 ? d.packed_rgb.p : nullptr, rgba_dev0 ? d.packed_rgba.p : nullptr, false, d.counters.p, d.stream)))
                         return fail(rc);
-                    uint32_t local_row = 0;
-                    for (uint64_t top = (uint64_t)i * strip_h; top < st->height; top += (uint64_t)n_scenes * strip_h) {
-                        const uint32_t h = (uint32_t)(st->height - top < strip_h ? st->height - top : strip_h);
-                        if (rgb_dev0 && !hip(hipMemcpyPeerAsync((char*)rgb_dev0 + top * st->width * 12, dev0, (char*)d.packed_rgb.p + (size_t)local_row * st->width * 12, d.device,
-                                                               (size_t)h * st->width * 12, d.stream), "hipMemcpyPeerAsync")) return;
-                        if (rgba_dev0 && !hip(hipMemcpyPeerAsync((char*)rgba_dev0 + top * st->width * 4, dev0, (char*)d.packed_rgba.p + (size_t)local_row * st->width * 4, d.device,
-                                                                (size_t)h * st->width * 4, d.stream), "hipMemcpyPeerAsync")) return;
-                        local_row += h;
-                    }
+                    if (rgb_dev0 && !hip(hipMemcpyPeerAsync(d.staging.p, dev0, d.packed_rgb.p, d.device, np * 12, d.stream), "hipMemcpyPeerAsync")) return;
+                    if (rgba_dev0 && !hip(hipMemcpyPeerAsync(d.staging_rgba.p, dev0, d.packed_rgba.p, d.device, np * 4, d.stream), "hipMemcpyPeerAsync")) return;
                 }
             }
         } else {
@@ -2900,6 +2954,15 @@ int rt_render_frame_multi(RtScene* const* scenes, uint32_t n_scenes, const RtSet
         for (uint32_t i = 0; i < n_scenes; i++)
             if (mc->dev[i].device != dev0) { if (int rc = mc->dev[i].staging.ensure(npix * 12)) return rc; }
         if (int rc = mc->total.ensure(npix * 12 + (size_t)n_scenes * sizeof(float*))) return rc;
+    } else {
+        HIP_TRY(hipSetDevice(dev0));
+        for (uint32_t i = 0; i < n_scenes; i++) {
+            if (mc->dev[i].direct) continue;
+            const int pw = rt_tile_columns_width(st->width, i, n_scenes);
+            if (pw <= 0) continue;
+            if (rgb_dev0) { if (int rc = mc->dev[i].staging.ensure((size_t)pw * st->height * 12)) return rc; }
+            if (rgba_dev0) { if (int rc = mc->dev[i].staging_rgba.ensure((size_t)pw * st->height * 4)) return rc; }
+        }
     }
     {
         std::vector<std::thread> threads;
@@ -2918,6 +2981,22 @@ int rt_render_frame_multi(RtScene* const* scenes, uint32_t n_scenes, const RtSet
     }
     if (first_rc != RT_OK) return set_error(first_rc, first_error);
     HIP_TRY(hipSetDevice(dev0));
+    if (mode == RT_MULTI_TILES) {
+        // replicas that could not write GPU 0's frame themselves: their packed columns were copied here; put them in place
+        hipStream_t s = mc->dev[0].stream;
+        bool any = false;
+        for (uint32_t i = 0; i < n_scenes; i++) {
+            if (mc->dev[i].direct) continue;
+            const int pw = rt_tile_columns_width(st->width, i, n_scenes);
+            if (pw <= 0) continue;
+            const uint32_t np = (uint32_t)pw * st->height;
+            hipLaunchKernelGGL(unpack_columns_kernel, dim3((np + 255) / 256), dim3(256), 0, s, rgb_dev0 ? (const float*)mc->dev[i].staging.p : nullptr,
+                               rgba_dev0 ? (const uint8_t*)mc->dev[i].staging_rgba.p : nullptr, (uint32_t)pw, np, n_scenes, i, (float*)rgb_dev0, (uint8_t*)rgba_dev0, st->width);
+            HIP_TRY_SYNC(hipGetLastError(), s);
+            any = true;
+        }
+        if (any) HIP_TRY(hipStreamSynchronize(s));
+    }
     if (mode == RT_MULTI_SPP) {
         // sum in replica order on GPU 0, then col / spp and v3_to_rgba (implementation.rs:659, src/rgba.rs:6-12)
         std::vector<const float*> parts(n_scenes);

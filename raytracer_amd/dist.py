@@ -145,6 +145,59 @@ class InterleavedCompositor:
         return self.frame
 
 
+def columns_of_rank(width, rank, world):
+    """Image column of every packed column of `rank` under the dealt tile-column partition (8-pixel tile columns rank, rank + world, ...)."""
+    out, tiles_x = [], (width + 7) // 8
+    for tx in range(rank, tiles_x, world):
+        out.extend(range(tx * 8, min(tx * 8 + 8, width)))
+    return out
+
+
+class ColumnCompositor:
+    """The finer tile partition: rank r owns the 8-pixel-wide tile columns r, r + world, r + 2 * world, ... over the whole height
+    (rt_render_tile_columns_device renders them in one launch into `.packed`, `height` rows of `.my_width` pixels); one gather later
+    rank `dst` scatters the columns into `.frame` with a precomputed column index.  Every rank holds a share of every region of the
+    image, which 8-row strips do not give (per-rank times of an 8-rank split: DESIGN.md section 6)."""
+
+    def __init__(self, width, height, rank, world, device, channels=3, dtype=torch.float32, dst=0):
+        from .scene import tile_columns_width
+        self.width, self.height, self.rank, self.world, self.dst = width, height, rank, world, dst
+        self.widths = [tile_columns_width(width, r, world) for r in range(world)]
+        assert sum(self.widths) == width
+        self.my_width = self.widths[rank]
+        max_w = max(max(self.widths), 1)
+        self._packed_full = torch.zeros((height * max_w, channels), dtype=dtype, device=device)
+        # (a rank's launch writes rows of ITS width: the leading height * my_width pixels of the buffer)
+        self.packed = self._packed_full[:height * self.my_width].view(height, self.my_width, channels) if self.my_width else self._packed_full[:0]
+        self.gathered = self.frame = self.col_index = None
+        if rank == dst:
+            self._all = torch.zeros((world, height * max_w, channels), dtype=dtype, device=device)
+            self.gathered = [self._all[r] for r in range(world)] if world > 1 else None
+            self.frame = torch.zeros((height, width, channels), dtype=dtype, device=device)
+            self.col_index = [torch.tensor(self.image_columns(r), dtype=torch.long, device=device) for r in range(world)]
+
+    def image_columns(self, r):
+        """Image column of every packed column of rank r."""
+        return columns_of_rank(self.width, r, self.world)
+
+    def composite(self):
+        got = None
+        if self.world > 1:
+            got = _gather(self._packed_full, self.gathered, self.dst, self.rank, self.world)
+        if self.rank != self.dst:
+            return None
+        if got is not None and got is not self.gathered:
+            for r in range(self.world):
+                self._all[r].copy_(got[r])
+        for r in range(self.world):
+            w = self.widths[r]
+            if w == 0:
+                continue
+            src = (self._all[r] if self.world > 1 else self._packed_full)[:self.height * w].view(self.height, w, -1)
+            self.frame.index_copy_(1, self.col_index[r], src)      # one scatter per rank: its packed columns to their image columns
+        return self.frame
+
+
 def reduce_accumulators(acc, rank, world, dst=0, how="ordered"):
     """Sum the per-rank accumulators onto rank `dst`.
 

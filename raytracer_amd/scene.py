@@ -341,6 +341,11 @@ class Scene:
         self._check(self._lib.rt_render_strips_device(self._h, C.byref(settings.c), strip_height, strip_first,
                                                       strip_period, seed, rgb_ptr, rgba_ptr, counters_ptr, stream))
 
+    def render_tile_columns_device(self, settings, col_first, col_period, seed, rgb_ptr, rgba_ptr, counters_ptr=None, stream=None):
+        """Every col_period-th 8-pixel tile column of the frame, one launch, packed output columns (tile_columns_width pixels per row)."""
+        self._check(self._lib.rt_render_tile_columns_device(self._h, C.byref(settings.c), col_first, col_period, seed, rgb_ptr, rgba_ptr,
+                                                            counters_ptr, stream))
+
     def accumulate_chunk_device(self, settings, chunk, seed, sample_first, sample_count, accum_ptr,
                                 counters_ptr=None, stream=None):
         self._check(self._lib.rt_accumulate_chunk_device(self._h, C.byref(settings.c), C.byref(chunk), seed,
@@ -399,6 +404,14 @@ def strip_rows(height, strip_height, strip_first, strip_period):
     n = _ffi.load_hip().rt_strip_rows(height, strip_height, strip_first, strip_period)
     if n < 0:
         raise RtError(n, "bad strip arguments")
+    return n
+
+
+def tile_columns_width(width, col_first, col_period):
+    """Packed width in pixels of the tile columns col_first, col_first + col_period, ... (rt_tile_columns_width)."""
+    n = _ffi.load_hip().rt_tile_columns_width(width, col_first, col_period)
+    if n < 0:
+        raise RtError(n, "bad tile-column arguments")
     return n
 
 

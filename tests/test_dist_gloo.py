@@ -136,3 +136,51 @@ def test_strip_rows_cover_the_image():
         for world in (1, 2, 3, 8):
             for sh in (8, 16):
                 assert sum(strip_rows(h, sh, r, world) for r in range(world)) == h
+
+
+def _worker_columns(rank, world, port, result_path):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from raytracer_amd import CameraConfiguration, RenderChunk, RenderSettings, SceneBuilder
+        from raytracer_amd.dist import ColumnCompositor
+        from tests.oracle import ORC_RNG_COUNTER, OracleScene
+        b = SceneBuilder.sample("Random Spheres", CameraConfiguration(W, H))
+        o = OracleScene(b)
+        st = RenderSettings(W, H, DEPTH, 3)
+        comp = ColumnCompositor(W, H, rank, world, torch.device("cpu"))
+        cols = comp.image_columns(rank)
+        assert len(cols) == comp.my_width
+        # the oracle stands in for rt_render_tile_columns_device: tile column by tile column into the packed columns
+        i = 0
+        while i < len(cols):
+            n = 1
+            while i + n < len(cols) and cols[i + n] == cols[i] + n and n < 8:
+                n += 1
+            rgb, _, _ = o.render_chunk(st, RenderChunk(cols[i], 0, n, H), ORC_RNG_COUNTER, SEED)
+            comp.packed[:, i:i + n] = torch.from_numpy(rgb)
+            i += n
+        frame = comp.composite()
+        if rank == 0:
+            full, _, _ = o.render_chunk(st, RenderChunk(0, 0, W, H), ORC_RNG_COUNTER, SEED)
+            np.save(result_path, np.array([float(np.array_equal(frame.numpy(), full))]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_gloo_dealt_tile_columns(tmp_path):
+    result = str(tmp_path / "ok.npy")
+    mp.spawn(_worker_columns, args=(2, _free_port(), result), nprocs=2, join=True)
+    assert np.load(result)[0] == 1.0
+
+
+def test_tile_column_widths_cover_the_image():
+    sys.path.insert(0, ROOT)
+    from raytracer_amd import tile_columns_width
+    for w in (1, 5, 8, 26, 63, 64, 65, 1920, 3840):
+        for world in (1, 2, 3, 8, 16):
+            widths = [tile_columns_width(w, r, world) for r in range(world)]
+            assert sum(widths) == w and all(x >= 0 for x in widths)
+            # only the owner of the frame's last tile column can hold a narrower one
+            assert sum(1 for x in widths if x % 8) <= 1
