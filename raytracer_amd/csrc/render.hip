@@ -833,7 +833,11 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                     {
                         const uint32_t x0 = (blk_tile % P.tiles_x) * 8u, y0 = (blk_tile / P.tiles_x) * 8u;
                         blk_xy0 = x0 | (y0 << 16);
+#ifdef RT_NO_TILE_COLUMNS      /* measurement only: what the column mapping costs the kernel */
+                        blk_px0 = P.left + x0;
+#else
                         blk_px0 = P.col_n ? ((x0 >> 3) * P.col_n + P.col_r) * 8u : P.left + x0;      // (dealt tile columns: rt_render_tile_columns_device)
+#endif
                         // (strips are whole rows of tiles, so the 8 rows of a tile are consecutive image rows)
                         blk_py0 = P.strip_h ? P.strip_first_row + (y0 / P.strip_h) * P.strip_period_rows + (y0 % P.strip_h) : P.top + y0;
                     }
