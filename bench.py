@@ -306,12 +306,11 @@ def oracle_legs(m, args, n_gpus, cpu_leg=True, cpu_seconds=None):
                 counter_frac = counter_flops_per_ray * rays_per_launch / kernel_s / 1e12 / VALU_PEAK_TFLOPS
         except Exception:
             counter_frac = counter_flops_per_ray = None
-    if traffic is not None and pmc_key != m["workload"]:
-        traffic = None
-    if traffic is None and os.path.exists(pmc_path) and n_gpus == 1 and pmc_key != m["workload"]:
+    traffic_key = PMC_WORKLOAD.get(m["workload"], m["workload"])
+    if traffic is None and os.path.exists(pmc_path) and n_gpus == 1 and traffic_key != m["workload"]:
         try:          # per-launch bytes of the 64-spp frame, scaled to this launch's rays (the traffic is the segment sums and per-ray spills)
-            t64 = json.load(open(pmc_path)).get(pmc_key)
-            r64 = json.load(open(cnt_path)).get(pmc_key, {}).get("rays_per_launch")
+            t64 = json.load(open(pmc_path)).get(traffic_key)
+            r64 = json.load(open(cnt_path)).get(traffic_key, {}).get("rays_per_launch")
             traffic = int(t64 * rays_per_launch / r64) if t64 and r64 else None
         except Exception:
             traffic = None
