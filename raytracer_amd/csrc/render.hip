@@ -638,6 +638,7 @@ struct RenderParams {
     unsigned long long* phase_stats;                // diagnostics build only: [phase][lane-iterations, wave-iterations]
 #endif
     uint32_t strip_h, strip_period_rows, strip_first_row;   // strip_h != 0: local row y -> image row (interleaved strips)
+    uint32_t single_rounds;                         // RT_SINGLE_ROUNDS_EXPERIMENT build: 1 = a claim covers one round of a block (whole-segment units only)
     uint32_t col_n, col_r;                          // col_n != 0: the chunk is the packed tile columns col_r, col_r + col_n, ... of the frame (local tile column j -> image tile column j * col_n + col_r)
 };
 
@@ -747,6 +748,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
     uint32_t pxy = 0, s = RT_NONE;           // pixel (x | y << 16) and sample index of the lane's current round (RT_NONE: no sample)
     // the wave's current block (wave-uniform): tile, unit, rounds started
     uint32_t blk_tile = 0, blk_unit = 0, round_next = 0, blk_lens = 0;
+    uint32_t round_first = 0, round_end = 0;    // the rounds of the block this claim covers: all of them, or ONE (P.single_rounds)
     uint32_t blk_xy0 = 0, blk_py0 = 0, blk_px0 = 0;   // the tile's first pixel: chunk-local x | y << 16, its image row and its image column
     F3 sample_col = f3(0, 0, 0);
     Pending pend[RT_PENDING_MAX]; uint32_t npend = 0;
@@ -794,7 +796,17 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                 // (same-address atomics serialise in L2: one counter cost 3 % of the headline frame and
                 // half of a single-sample launch).  A wave starts at its own counter and moves on to the
                 // next one when that is exhausted, so the hand-out order stays "expensive first".
-                const uint32_t total_blocks = total_items >> 6;          // pix_slots is a multiple of 64
+                // RT_SINGLE_ROUNDS_EXPERIMENT (`make singlerounds`, RT_SINGLE_ROUNDS=1): a claim is ONE round of a block (64 samples instead of 512), against the tail of launches
+                // with few blocks per resident wave (one rank's share of an N-GPU frame).  Claims 8b .. 8b + 7 are the rounds of block b; the eight rounds of a LENS-CELL block are
+                // chained through one output slot, so its claim 8b runs all of them and 8b + 1 .. 7 are empty.  Same pixels (176 parity tests); measured a loss everywhere - a claim is an
+                // atomic round trip, a dependent read of the tile order and four integer divisions: full frames -25 % (weekend), -17 % (Dreadnaught), -7 % (mesh_demo), and the slowest
+                // of 8 ranks no earlier: what spreads the ranks is the cost of a block's 8 PIXELS, not the number of its rounds.
+#ifdef RT_SINGLE_ROUNDS_EXPERIMENT
+                const uint32_t single_rounds = P.single_rounds;
+#else
+                constexpr uint32_t single_rounds = 0u;
+#endif
+                const uint32_t total_blocks = single_rounds ? (total_items >> 6) << 3 : total_items >> 6;          // pix_slots is a multiple of 64
                 uint32_t blk = total_blocks;
                 // Cancellation (the reference checks its token per work item and per pixel, src/render.rs:131,149).  A read of the scene's host-mapped
                 // cancel word crosses the host link and costs microseconds - done by every wave at every 4th claim it halved the headline frame rate
@@ -816,9 +828,11 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                 }
                 // progress (src/render.rs:156-158 sends a snapshot every 800 ms): the queues advance evenly, so the number of the block just claimed
                 // is about the number of blocks handed out; the pollers store it (plain stores, last writer wins - an estimate, not a count)
-                if (poller && lane == 0 && blk < total_blocks) __hip_atomic_store(P.progress_word, P.progress_base + blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (poller && lane == 0 && blk < total_blocks) __hip_atomic_store(P.progress_word, P.progress_base + (single_rounds ? blk >> 3 : blk), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 if (blk >= total_blocks) state = FINISHED;
                 else {
+                    round_first = 0u; round_end = P.unit_len;
+                    if (single_rounds) { round_first = blk & 7u; round_end = round_first + 1u; blk >>= 3; }
                     // Block numbering: first every unit of each tile whose rays hit something, tile after
                     // tile in cost order (so that the long blocks all start early), then the tiles that
                     // see only sky, unit by unit over the whole image.
@@ -853,8 +867,13 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                         blk_lens |= (t << 1) | ((unit_local & ((1u << k) - 1u)) << 3);
                         blk_unit = t ? ((m >> t) << (k + t)) + (m & ((1u << t) - 1u)) : (m << k);
                     }
-                    round_next = 0u; s = RT_NONE;         // the block's rays are dealt to the lanes round by round, below
+                    s = RT_NONE;                          // the block's rays are dealt to the lanes round by round, below
                     state = NEED_SAMPLE;
+                    if (single_rounds && DOF && (blk_lens & 1u)) {      // a lens-cell block: whole, under its first claim
+                        if (round_first != 0u) state = NEED_BLOCK;
+                        round_end = P.unit_len;
+                    }
+                    round_next = round_first;
                 }
             }
             if (__ballot(state != FINISHED) == 0ull) break;      // the wave has no blocks left
@@ -1043,7 +1062,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                 y = ((z >> 1) & 1u) | ((z >> 2) & 2u) | ((z >> 3) & 4u);
             };
             for (;;) {
-                if (round_next != 0u) {
+                if (round_next != round_first) {
                     // close the round: segment sums of its pixels, ((0 + c0) + c1) + ... in sample order
                     const F3 c = s != RT_NONE ? sample_col : f3(0.0f, 0.0f, 0.0f);     // (x + 0 == x: the sum is never -0)
                     F3 sum = f3(0.0f, 0.0f, 0.0f);
@@ -1065,7 +1084,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                         out[0] = sum.x; out[1] = sum.y; out[2] = sum.z;
                     }
                 }
-                if (round_next == P.unit_len) { state = NEED_BLOCK; break; }      // wait for the wave's next block
+                if (round_next == round_end) { state = NEED_BLOCK; break; }      // wait for the wave's next block
                 uint32_t x, y; round_pixel(round_next, x, y);
                 round_next++;
                 if (lens) { const uint32_t sl = s_mine + (round_next - 1u); s = (x0 + x < P.cw && y0 + y < P.ch && sl >= P.sample_first && sl < P.sample_first + P.sample_count) ? sl : RT_NONE; }
@@ -2056,6 +2075,8 @@ int enqueue_accumulate(RtScene* scene, Workspace& ws, const RtSettings* st, cons
             while (!fine && P.round_units_shift < max_shift && P.unit_count % (2u << P.round_units_shift) == 0) P.round_units_shift++;
             // (without the stratified sampler the samples of one index do not share a lens cell: nothing to gain from that round shape)
             if (P.round_units_shift != 3u || !P.lens_stratify) P.lens_rounds = 0u;
+            static const bool single = []() { const char* e = getenv("RT_SINGLE_ROUNDS"); return e && atoi(e) != 0; }();      // (only the RT_SINGLE_ROUNDS_EXPERIMENT build looks at it)
+            P.single_rounds = (single && !fine && unit_len == RT_SAMPLE_SEGMENT) ? 1u : 0u;
         }
         const uint64_t items = (uint64_t)P.pix_slots * P.unit_count;
         uint64_t blocks = (items + RT_BLOCK - 1) / RT_BLOCK;
