@@ -800,7 +800,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                 // with few blocks per resident wave (one rank's share of an N-GPU frame).  Claims 8b .. 8b + 7 are the rounds of block b; the eight rounds of a LENS-CELL block are
                 // chained through one output slot, so its claim 8b runs all of them and 8b + 1 .. 7 are empty.  Same pixels (176 parity tests); measured a loss everywhere - a claim is an
                 // atomic round trip, a dependent read of the tile order and four integer divisions: full frames -25 % (weekend), -17 % (Dreadnaught), -7 % (mesh_demo), and the slowest
-                // of 8 ranks no earlier: what spreads the ranks is the cost of a block's 8 PIXELS, not the number of its rounds.
+                // of 8 ranks no earlier: the expensive tiles of mesh_demo are lens-cell blocks, which stay one claim.
 #ifdef RT_SINGLE_ROUNDS_EXPERIMENT
                 const uint32_t single_rounds = P.single_rounds;
 #else

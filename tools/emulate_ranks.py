@@ -44,6 +44,8 @@ for workload in ([a for a in sys.argv[1:] if a != "--strips"] or ["dreadnaught-1
                     best = dt
             steps.append(best); kernels.append(best_k)
         slow = max(steps)
+        if os.environ.get("EMULATE_VERBOSE"):
+            print("   per rank, kernel ms:", " ".join(f"{k:.2f}" for k in kernels), flush=True)
         if world == 1:
             one = slow
         fixed = [s - k for s, k in zip(steps, kernels)]
