@@ -766,6 +766,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
     float t_min = 0.0f, t_max = 0.0f, best_t = 0.0f;
     Hit best; best.t = 0.0f; best.ent = RT_NONE; best.tri = RT_NONE; best.erank = 0;      // (erank: unused here, ranks are fetched on ties)
     uint32_t cur = RT_NONE, sp = 0, inst_sp = RT_NONE, tri_base = 0, cur_ent = 0;
+    float ray_dd = 0.0f;                     // ECACHE: |d|^2 of the ray in flight (sphere.rs:6 forms it per test; the same product every time)
 
     // Node cache: the scene's first S.lds_nodes records (the top levels of the TLAS and of every BLAS,
     // scene_build.cpp) are read from LDS instead of through the vector memory path: the texture
@@ -782,8 +783,11 @@ render_kernel(const DevSceneView S, const RenderParams P) {
     static_assert(!ECACHE || (SPHERES && !MESH && !PLANES && !XFORMS && !LOOSE), "the sphere cache holds word 0 of the entity records only");
     uint32_t* const ent_cache = node_cache + S.lds_nodes * (RT_NODE_CACHE_STRIDE / 4u);
     if (ECACHE)
-        for (uint32_t i = threadIdx.x; i < S.lds_ents; i += RT_BLOCK)
-            *reinterpret_cast<float4*>(ent_cache + i * 4u) = *reinterpret_cast<const float4*>(&S.entities[i].w[0]);
+        for (uint32_t i = threadIdx.x; i < S.lds_ents; i += RT_BLOCK) {
+            float4 v = *reinterpret_cast<const float4*>(&S.entities[i].w[0]);
+            v.w = v.w * v.w;                              // (radius * radius, the product sphere.rs:8 forms per test)
+            *reinterpret_cast<float4*>(ent_cache + i * 4u) = v;
+        }
     __syncthreads();
 
     for (;;) {
@@ -1163,6 +1167,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                 cur = slab(S.tlas_min[0], S.tlas_min[1], S.tlas_min[2], S.tlas_max[0], S.tlas_max[1], S.tlas_max[2], o, inv, t_min, best_t, e)
                           ? S.tlas_root_ref : RT_NONE;
                 tracing = true;
+                if (ECACHE) ray_dd = dot(d, d);
             }
         }
         if (__ballot(tracing) == 0ull) continue;   // nothing to traverse: the wave is between blocks
@@ -1268,7 +1273,8 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                         PH(PH_LEAF_TLAS);
                         TM(TM_LEAF_TLAS);
                         const bool shadow = state == SHADOW;
-                        const F3 wo = shadow ? hp : ro, wd = shadow ? -ldir : rd;
+                        // (without mesh instances the walk never leaves world space: o and d ARE the world ray)
+                        const F3 wo = MESH ? (shadow ? hp : ro) : o, wd = MESH ? (shadow ? -ldir : rd) : d;
                         bool entered = false;
                         for (uint32_t k = 0; k < count && !entered; k++) {
                             PH(PH_ENTITY);
@@ -1308,9 +1314,9 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                             if (SPHERES && ((!MESH && !PLANES) || kind == RT_HITABLE_SPHERE)) {
                                 // intersect_sphere + Sphere::hit, sphere.rs:4-17, 36-39
                                 const float radius = e0.f[3];
-                                const float qa = dot(ed, ed);
+                                const float qa = ECACHE ? ray_dd : dot(ed, ed);      // (ECACHE: ed is the world ray's direction for every sphere of the ray)
                                 const float qb = dot(eo, ed);
-                                const float qc = dot(eo, eo) - radius * radius;
+                                const float qc = dot(eo, eo) - (ECACHE ? radius : radius * radius);      // (ECACHE: the cache holds the product)
                                 const float discriminant = qb * qb - qa * qc;
                                 if (discriminant > 0.0f) {
                                     const float sq = sqrtf(discriminant);
