@@ -751,24 +751,12 @@ render_kernel(const DevSceneView S, const RenderParams P) {
     uint32_t round_first = 0, round_end = 0;    // the rounds of the block this claim covers: all of them, or ONE (P.single_rounds)
     uint32_t blk_xy0 = 0, blk_py0 = 0, blk_px0 = 0;   // the tile's first pixel: chunk-local x | y << 16, its image row and its image column
     F3 sample_col = f3(0, 0, 0);
-    Pending pend[RT_PENDING_MAX + 1]; uint32_t npend = 0;      // (+ 1: the free slot above the list parks the tinted light colour of a shadow ray, below)
+    Pending pend[RT_PENDING_MAX]; uint32_t npend = 0;
     F3 ro = f3(0, 0, 0), rd = f3(0, 0, 1), rw = f3(0, 0, 0); uint32_t rlimit = 0, rnode = 0;   // current path ray
     F3 hp = f3(0, 0, 0), hn = f3(0, 0, 0), wa = f3(0, 0, 0), lsum = f3(0, 0, 0);                  // light phase
     float li = 0.0f;
     uint32_t light_k = 0;
-    F3 ldir = f3(0, 0, 1); float l_t = 0.0f, closest = 0.0f;
-    // The light colour of the shadow ray in flight (light_color, implementation.rs:531) is NOT carried through the walk: three registers the compiler spilled
-    // to the private segment around every shadow ray (6 scratch instructions per shadow ray: 40 % of the 900-instance frame's vector-memory writes).  It is formed
-    // again after the walk, with light_record's own operations, from the light's record and l_t; once a dielectric has tinted it (:541-543, rare) the running
-    // product waits in the private segment instead - in the free slot above the deferred-ray list, which does not move while a hit's lights are cast.
-    bool tinted = false;
-    auto light_colour = [&]() -> F3 {
-        if (tinted) return pend[npend].w;
-        const Word4* lw = S.lights[light_k].w;
-        const Word4 l0 = ldw(lw), l3 = ldw(lw + 3);
-        const float intensity = l0.u[0] == RT_LIGHT_DIRECTIONAL ? l0.f[1] : l0.f[1] / (4.0f * RT_PI * l_t);      // light_record: l_t is its t
-        return w3(l3) * intensity;
-    };
+    F3 lcol = f3(0, 0, 0), ldir = f3(0, 0, 1); float l_t = 0.0f, closest = 0.0f;
 
     // Traversal state of the ray in flight (resumable: survives leaving the burst).
     // The search itself is Scene::hit_closest (implementation.rs:372-375) =
@@ -903,7 +891,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                 n_shadow++;
                 state = NEED_LIGHT;
                 if (best.ent == RT_NONE) {
-                    lsum = lsum + (light_colour() * fmaxf(0.0f, dot(hn, -ldir)));                    // :615-619
+                    lsum = lsum + (lcol * fmaxf(0.0f, dot(hn, -ldir)));                    // :615-619
                     light_k++;
                 } else {
                     // Only a dielectric can let light through (scatter yields a refraction only
@@ -921,8 +909,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                         if (!(kr >= 1.0f)) {
                             const float refr_intensity = (1.0f - kr) * (1.0f - m0.f[3]);
                             const F3 albedo = texture_value<RICH>(S, hr.tex_id, hr);
-                            pend[npend].w = light_colour() * (albedo * refr_intensity);      // :541-543
-                            tinted = true;
+                            lcol = lcol * (albedo * refr_intensity);                          // :541-543
                             closest = best.t + RT_BIAS;
                             // NOT the reference: beyond t = 65 536 the sum rounds back to t, a plane or a triangle accepts t == t_min, and the
                             // reference's loop finds the same occluder for ever (the pixel never returns; here: a kernel that never ends).
@@ -1012,7 +999,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                 while (light_k < S.light_count) {
                     LightRec lr;
                     if (light_record<RICH>(S, light_k, hp, lr)) {
-                        ldir = lr.direction; l_t = lr.t; closest = RT_BIAS; tinted = false;   // :527-532 (light_color = lr.color * lr.intensity: light_colour(), above)
+                        lcol = lr.color * lr.intensity; ldir = lr.direction; l_t = lr.t; closest = RT_BIAS;   // :527-532
                         state = SHADOW;
                         break;
                     }
