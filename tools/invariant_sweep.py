@@ -1,7 +1,7 @@
 """One-off randomized sweep of the size-independent properties the parity suite checks on fixed sizes: for random scenes
 (tests/test_gpu_fuzz.py's generator) at random image sizes, sample counts, depths, lens settings and options, the frame must be
 bit-identical however it is produced -
-  whole frame == random chunk grid == strips of a random rank count == sample ranges accumulated and resolved
+  whole frame == random chunk grid == strips of a random rank count == dealt tile columns of the same rank count == sample ranges accumulated and resolved
   == rt_render_chunk_device_noalloc == the host-pointer call (rgb and rgba = `as u8` of the floats) == the same call again,
 and close to the oracle in the scene's lens mode.
    usage: python tools/invariant_sweep.py <first seed> <count>"""
@@ -9,7 +9,8 @@ import os, sys, time, traceback
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
-from raytracer_amd import RenderChunk, RenderSettings, Scene, create_render_chunks, resolve_device, sample_segment, strip_rows
+from raytracer_amd import RenderChunk, RenderSettings, Scene, create_render_chunks, resolve_device, sample_segment, strip_rows, tile_columns_width
+from raytracer_amd.dist import columns_of_rank
 from raytracer_amd.dist import sample_range_of_rank
 from tests.oracle import OracleScene, use_lens_mode
 from tests.test_gpu_fuzz import random_scene
@@ -69,6 +70,17 @@ def one(seed):
         out.index_copy_(0, idx, packed)
     torch.cuda.synchronize()
     assert torch.equal(out, frame), what + f": {world}-rank strips"
+    # dealt tile columns (the same number of ranks; no new random draw, so the cases stay those of the earlier sweeps)
+    out = buf()
+    for k in range(world):
+        pw = tile_columns_width(w, k, world)
+        if pw == 0:
+            continue
+        packed = torch.zeros((h, pw, 3), dtype=torch.float32, device=DEV)
+        scene.render_tile_columns_device(st, k, world, render_seed, packed.data_ptr(), None, None, sm)
+        out.index_copy_(1, torch.tensor(columns_of_rank(w, k, world), device=DEV), packed)
+    torch.cuda.synchronize()
+    assert torch.equal(out, frame), what + f": {world}-rank tile columns"
     # sample ranges
     parts = int(r.integers(2, 6))
     acc = buf()
