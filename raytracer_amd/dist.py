@@ -189,12 +189,16 @@ class ColumnCompositor:
         if got is not None and got is not self.gathered:
             for r in range(self.world):
                 self._all[r].copy_(got[r])
+        return self.assemble([self._all[r] for r in range(self.world)] if self.world > 1 else [self._packed_full])
+
+    def assemble(self, sources):
+        """Rank dst: the frame from every rank's packed buffer (sources[r] = rank r's `_packed_full`), one scatter per rank."""
         for r in range(self.world):
             w = self.widths[r]
             if w == 0:
                 continue
-            src = (self._all[r] if self.world > 1 else self._packed_full)[:self.height * w].view(self.height, w, -1)
-            self.frame.index_copy_(1, self.col_index[r], src)      # one scatter per rank: its packed columns to their image columns
+            src = sources[r][:self.height * w].view(self.height, w, -1)
+            self.frame.index_copy_(1, self.col_index[r], src)      # its packed columns to their image columns
         return self.frame
 
 

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from raytracer_amd import (CameraConfiguration, RenderChunk, RenderSettings, RtError, Scene, SceneBuilder, tile_columns_width)
-from raytracer_amd.dist import columns_of_rank
+from raytracer_amd.dist import ColumnCompositor, columns_of_rank
 
 pytestmark = pytest.mark.gpu
 
@@ -63,4 +63,24 @@ def test_tile_column_arguments():
     scene.render_tile_columns_device(st, 7, 8, 1, buf.data_ptr(), None, None, stream)
     torch.cuda.synchronize()
     assert tile_columns_width(40, 7, 8) == 0 and float(buf.min()) == -1.0 and float(buf.max()) == -1.0
+    scene.close()
+
+
+def test_column_compositor_assembles_the_frame_on_the_device():
+    """raytracer_amd.dist.ColumnCompositor (what bench.py --gpus N runs per rank) with device tensors: every rank renders into its own
+    compositor's send buffer, rank 0's compositor assembles them (the gather itself is torch.distributed's: tests/test_dist_gloo.py)."""
+    import torch
+    w, h, world = 150, 70, 4
+    scene = Scene(SceneBuilder.sample("Random Spheres", CameraConfiguration(w, h, lens_radius=0.1)), 0)
+    st = RenderSettings(w, h, 6, 8)
+    whole, _, _ = scene.render_chunk(st, RenderChunk(0, 0, w, h), seed=21)
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream().cuda_stream
+    comps = [ColumnCompositor(w, h, r, world, dev) for r in range(world)]
+    for r, c in enumerate(comps):
+        if c.my_width:
+            scene.render_tile_columns_device(st, r, world, 21, c.packed.data_ptr(), None, None, stream)
+    torch.cuda.synchronize()
+    frame = comps[0].assemble([c._packed_full for c in comps])
+    assert frame.is_contiguous() and np.array_equal(frame.cpu().numpy(), whole)
     scene.close()
