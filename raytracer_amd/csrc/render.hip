@@ -748,6 +748,10 @@ render_kernel(const DevSceneView S, const RenderParams P) {
     uint32_t pxy = 0, s = RT_NONE;           // pixel (x | y << 16) and sample index of the lane's current round (RT_NONE: no sample)
     // the wave's current block (wave-uniform): tile, unit, rounds started
     uint32_t blk_tile = 0, blk_unit = 0, round_next = 0, blk_lens = 0;
+#ifdef RT_CLAIM_AHEAD      /* measurement only: the next block claimed while this one starts, so that the atomic's round trip is hidden - one more register through the walk:
+                              weekend -0.8 %, Dreadnaught -1.5 %, mesh_demo -0.5 %, 900 instances -0.9 %, 400x225x16 -8 % (blocks held back by busy waves).  Not adopted. */
+    uint32_t next_idx = 0; bool have_next = false;      // the block claimed ahead (lane 0 holds its number)
+#endif
     uint32_t round_first = 0, round_end = 0;    // the rounds of the block this claim covers: all of them, or ONE (P.single_rounds)
     uint32_t blk_xy0 = 0, blk_py0 = 0, blk_px0 = 0;   // the tile's first pixel: chunk-local x | y << 16, its image row and its image column
     F3 sample_col = f3(0, 0, 0);
@@ -825,6 +829,10 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                 }
                 for (uint32_t tries = 0; tries < RT_QUEUES && blk >= total_blocks; tries++) {
                     uint32_t idx = 0;
+#ifdef RT_CLAIM_AHEAD
+                    if (tries == 0u && have_next) idx = next_idx;      // claimed while the last block was starting: its round trip is long over
+                    else
+#endif
                     if (lane == 0) idx = atomicAdd(P.block_counter + queue * 16u, 1u);
                     idx = __builtin_amdgcn_readfirstlane(idx);
                     blk = idx < (total_blocks + RT_QUEUES - 1u) / RT_QUEUES ? idx * RT_QUEUES + queue : total_blocks;      // (guards the multiply)
@@ -833,6 +841,10 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                 // progress (src/render.rs:156-158 sends a snapshot every 800 ms): the queues advance evenly, so the number of the block just claimed
                 // is about the number of blocks handed out; the pollers store it (plain stores, last writer wins - an estimate, not a count)
                 if (poller && lane == 0 && blk < total_blocks) __hip_atomic_store(P.progress_word, P.progress_base + (single_rounds ? blk >> 3 : blk), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#ifdef RT_CLAIM_AHEAD
+                have_next = blk < total_blocks;
+                if (have_next && lane == 0) next_idx = atomicAdd(P.block_counter + queue * 16u, 1u);      // the NEXT block of this queue; looked at when this one is done
+#endif
                 if (blk >= total_blocks) state = FINISHED;
                 else {
                     round_first = 0u; round_end = P.unit_len;
