@@ -3009,7 +3009,10 @@ int rt_render_frame_multi(RtScene* const* scenes, uint32_t n_scenes, const RtSet
     }
     {
         std::vector<std::thread> threads;
-        for (uint32_t i = 1; i < n_scenes; i++) threads.emplace_back(work, i);
+        for (uint32_t i = 1; i < n_scenes; i++) {
+            try { threads.emplace_back(work, i); }
+            catch (...) { work(i); }          // (no thread to be had: this replica's share is enqueued from here - later, not never)
+        }
         work(0);
         for (auto& t : threads) t.join();
     }
