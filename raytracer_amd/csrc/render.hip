@@ -687,7 +687,7 @@ enum { TM_OTHER = 0, TM_NODE, TM_LEAF_TRI, TM_LEAF_TLAS, TM_SHADE, TM_ROUNDS, TM
 #define TM(i) do { } while (0)
 #endif
 #ifdef RT_PHASE_STATS
-enum { PH_NODE = 0, PH_TRI, PH_ENTITY, PH_SHADE, PH_SHADE_PATH_HIT, PH_SHADE_SHADOW_HIT, PH_STAGE_A, PH_STAGE_C, PH_TRACE_INIT, PH_BURST, PH_LEAF_TRI, PH_LEAF_TLAS, PH_OUTER, PH_POP_INST, PH_COUNT };
+enum { PH_NODE = 0, PH_TRI, PH_ENTITY, PH_SHADE, PH_SHADE_PATH_HIT, PH_SHADE_SHADOW_HIT, PH_STAGE_A, PH_STAGE_C, PH_TRACE_INIT, PH_BURST, PH_LEAF_TRI, PH_LEAF_TLAS, PH_OUTER, PH_POP_INST, PH_NODE_GLOBAL, PH_NODE_NOT_II, PH_INST_HEADER, PH_COUNT };
 #ifdef RT_PHASE_TIME
 #define PH(i) do { } while (0)
 #else
@@ -1227,6 +1227,10 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                         // (32-bit byte offset from the uniform base: one shift instead of a 64-bit shift and add; rt_scene_create refuses scenes of 2^26 records)
                         const Word4* n = reinterpret_cast<const Word4*>(reinterpret_cast<const char*>(S.nodes) + (cur << 6));
                         na = ldw(n); nb = ldw(n + 1); nc = ldw(n + 2); nr = ldw(n + 3);
+#if defined(RT_PHASE_STATS) && !defined(RT_PHASE_TIME)      /* how many record reads from memory are of records with two INNER children (what a compact inner record could save) */
+                        PH(PH_NODE_GLOBAL);
+                        if (!(nr.u[0] < RT_REF_LEAF_BIT && nr.u[1] < RT_REF_LEAF_BIT)) PH(PH_NODE_NOT_II);
+#endif
 #ifdef RT_EXTRA_NODE_LOAD      /* measurement only: what ONE more 16-byte read of the same line costs per node step - the slope along which a 48-byte record would gain */
                         { typedef float v4f __attribute__((ext_vector_type(4))); const v4f extra = *reinterpret_cast<const volatile v4f*>(n + 3); asm volatile("" ::"v"(extra.x), "v"(extra.y), "v"(extra.z), "v"(extra.w)); }
 #endif
@@ -1351,6 +1355,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                                 }
                             } else if (MESH) {
                                 // MeshObject::hit -> BLAS (mesh.rs:161-176): enter the instance
+                                PH(PH_INST_HEADER);
                                 const Word4* mw = rec32(S.meshes, e1.u[1], (uint32_t)sizeof(DevMesh));
                                 const Word4 m0 = ldw(mw), m1 = ldw(mw + 1), m2 = ldw(mw + 2);
                                 const F3 einv = f3(1.0f / ed.x, 1.0f / ed.y, 1.0f / ed.z);
@@ -2160,7 +2165,7 @@ int enqueue_accumulate(RtScene* scene, Workspace& ws, const RtSettings* st, cons
             for (int k = 0; k < TM_COUNT; k++)
                 fprintf(stderr, "time  %-18s %6.2f %% of the wave cycles (%llu waves)\n", tnames[k], total ? 100.0 * (double)h[2 * k] / (double)total : 0.0, h[2 * k + 1]);
 #else
-            static const char* names[PH_COUNT] = {"node", "tri", "entity", "shade", "shade_path_hit", "shade_shadow_hit", "stage_a", "stage_c", "trace_init", "burst", "leaf_tri", "leaf_tlas", "outer", "pop_inst"};
+            static const char* names[PH_COUNT] = {"node", "tri", "entity", "shade", "shade_path_hit", "shade_shadow_hit", "stage_a", "stage_c", "trace_init", "burst", "leaf_tri", "leaf_tlas", "outer", "pop_inst", "node_global", "node_not_ii", "inst_header"};
             for (int k = 0; k < PH_COUNT; k++)
                 fprintf(stderr, "phase %-18s lanes %14llu passes %12llu util %.3f\n", names[k], h[2 * k], h[2 * k + 1], h[2 * k + 1] ? (double)h[2 * k] / (64.0 * (double)h[2 * k + 1]) : 0.0);
             for (int k = 1; k < 8; k++) {      // bursts by the kinds of ray they hold: c camera, s secondary, h shadow
