@@ -207,14 +207,17 @@ def measure(workload, args, ctx, mode=None, reduce=None, steps=None, warmup=None
     kernel_ms, launches = scene.profile_read()       # HIP events around every render_kernel launch, on its stream
     scene.profile_enable(False)
 
-    cn = counters.clone()
-    local_rays = int(cn[:3].sum().item())          # this rank's rays: what its own kernel launches traced
+    # camera rays in EMPTY tiles (every camera ray of the tile misses the scene's root box under a black sky: one packet test per tile instead of 64 x spp ray tests,
+    # rt_hip.h RT_OPT_CULL_EMPTY_TILES): counted as the rays they are for the reference (hit_closest is called and misses at the root) and by the CPU leg, never traced here
+    local_culled = scene.culled_pixels() * (spp if args.mode == "tiles" else s_count)     # per step, this rank
+    cn = torch.cat([counters, torch.tensor([local_culled], dtype=torch.int64, device=dev)])
+    local_rays = int(cn[:3].sum().item())          # this rank's rays: what its own kernel launches traced (+ its empty tiles' camera rays)
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if dist is not None:
         dist.all_reduce(cn, op=dist.ReduceOp.SUM)
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
-    primary, secondary, shadow, samples = [int(v) for v in cn.tolist()]
+    primary, secondary, shadow, samples, culled = [int(v) for v in cn.tolist()]
     rays = primary + secondary + shadow
     scene.close()
     if rank != 0:
@@ -229,9 +232,10 @@ def measure(workload, args, ctx, mode=None, reduce=None, steps=None, warmup=None
                    "mode": args.mode, "parallelism": parallelism},
         "rccl_ranks": ctx["world"] if dist is not None else 0,
         "msamples_per_s": round(samples / elapsed / 1e6, 3), "writes": "float3",
-        "rays_per_step": {"primary": primary // args.steps, "secondary": secondary // args.steps, "shadow": shadow // args.steps},
+        "rays_per_step": {"primary": primary // args.steps, "secondary": secondary // args.steps, "shadow": shadow // args.steps,
+                          "primary_in_empty_tiles": culled},
     }
-    return dict(line=line, builder=builder, settings=settings, info=info, kernel_ms=kernel_ms, launches=launches, local_rays=local_rays,
+    return dict(line=line, builder=builder, settings=settings, info=info, kernel_ms=kernel_ms, launches=launches, local_rays=local_rays, local_culled=local_culled,
                 W=W, H=H, spp=spp, depth=depth, workload=workload, steps=args.steps)
 
 
@@ -278,6 +282,9 @@ def oracle_legs(m, args, n_gpus, cpu_leg=True, cpu_seconds=None):
     kernel_s = m["kernel_ms"] / 1e3 / launches
     rays_per_launch = m["local_rays"] / launches           # rank 0's launches (N > 1: its share of the frame)
     tflops = flops_per_ray * rays_per_launch / kernel_s / 1e12
+    # the same without the camera rays of empty tiles, which the model prices (one box test + the sky) and the kernel never traces
+    culled_per_launch = m.get("local_culled", 0) * m["steps"] / launches
+    tflops_traced = (flops_per_ray * rays_per_launch - culled_per_launch * (F_AABB + F_SHADE)) / kernel_s / 1e12
     # algorithmic HBM bytes of one launch: the scene once + one float3 segment sum per work item
     segs = (spp + sample_segment() - 1) // sample_segment()
     hbm_bytes_per_launch = (int(info.device_bytes) + W * H * segs * B_PIXEL // n_gpus) * (m["steps"] / launches)
@@ -317,6 +324,7 @@ def oracle_legs(m, args, n_gpus, cpu_leg=True, cpu_seconds=None):
     line["roofline"] = {
         "bound": "valu", "achieved": round(tflops, 4), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
         "frac": round(tflops / VALU_PEAK_TFLOPS, 5), "traffic": traffic,
+        "frac_traced": round(tflops_traced / VALU_PEAK_TFLOPS, 5), "rays_in_empty_tiles_per_launch": int(culled_per_launch),
         "counter_frac": None if counter_frac is None else round(counter_frac, 5),
         "counter_flops_per_ray": None if counter_flops_per_ray is None else round(counter_flops_per_ray, 2),
         "kernel": "render_kernel", "kernel_ms_avg": round(kernel_s * 1e3, 4), "launches": int(m["launches"]),

@@ -25,6 +25,7 @@ RT_SKY_DAY, RT_SKY_BLACK = 0, 1
 RT_DEVICE_HOST_ONLY = -1
 # rt_scene_set_option
 RT_OPT_LENS_SAMPLER, RT_OPT_FINE_SPLIT, RT_OPT_ROUND_UNITS, RT_OPT_LENS_COC_PX, RT_OPT_DEBUG_STACK_ENTRIES = 1, 2, 3, 4, 100
+RT_OPT_CULL_EMPTY_TILES = 5
 RT_OPT_DEBUG_REBUILD_STACK_LIMIT = 101
 
 
@@ -192,6 +193,7 @@ HIP_PROTOTYPES = {
                                              _P(RtRayCounters)]),
     "rt_scene_cancel": (C.c_int, [C.c_void_p, C.c_int]),
     "rt_scene_progress": (C.c_int, [C.c_void_p, _P(C.c_uint64), _P(C.c_uint64)]),
+    "rt_scene_culled_pixels": (C.c_int, [C.c_void_p, _P(C.c_uint64)]),
 }
 
 SAMPLES_PROTOTYPES = {

@@ -612,6 +612,7 @@ __device__ __forceinline__ float dielectric_kr(F3 dir, F3 normal, float ref_inde
 // the render kernel
 // ===========================================================================
 struct Pending { F3 o, d, w; uint32_t limit, node; };
+#define RT_BIN_EMPTY 4u           /* cost class (classify_kernel) of a tile none of whose camera rays can meet the scene: sorted last, never handed out */
 
 struct RenderParams {
     uint32_t width, height, max_reflections, spp;   // RenderSettings
@@ -633,7 +634,9 @@ struct RenderParams {
     float* partial;                                 // [unit_count][tile][64][3] sums of the clamped samples of each unit (8x8 tiles of the chunk)
     unsigned long long* counters;                   // RtRayCounters on the device (nullable)
     uint32_t* block_counter;                        // RT_QUEUES counters, 64 B apart (zeroed per launch): next unclaimed block of each queue
-    const uint32_t* tile_order;                     // k-th tile to hand out, expensive ones first; [-1] = how many are expensive; null = row-major
+    const uint32_t* tile_order;                     // k-th tile to hand out, expensive ones first; [-1] = how many are expensive, [-2] = how many are handed out at all (the rest is empty, below); null = row-major
+    uint32_t cull_empty;                            // classify_kernel may find tiles EMPTY (every camera ray of the tile misses the root box, black sky): never handed out, their samples are zeros
+    uint32_t* culled_word;                          // host-mapped: valid pixels of the call's empty tiles (rt_scene_culled_pixels)
 #ifdef RT_PHASE_STATS
     unsigned long long* phase_stats;                // diagnostics build only: [phase][lane-iterations, wave-iterations]
 #endif
@@ -721,7 +724,9 @@ render_kernel(const DevSceneView S, const RenderParams P) {
     // to the next block together, so the rays of a wave stay spatially coherent.
     // Blocks are claimed dynamically (one atomic per wave and block), so waves that
     // drew cheap tiles simply take more of them.
-    const uint32_t total_items = P.pix_slots * P.unit_count;
+    // (empty tiles - classify_kernel - are sorted behind all others and never handed out: fold_kernel takes their samples as the zeros they are)
+    const uint32_t active_tiles = P.tile_order ? P.tile_order[-2] : P.pix_slots >> 6;
+    const uint32_t total_items = active_tiles * 64u * P.unit_count;
     const uint32_t lane = threadIdx.x & 63u;
 
     // (counting samples and camera rays on the host instead - both are known per launch - frees two registers and was measured: Dreadnaught +0.5 %, 900 instances +0.8 %,
@@ -840,7 +845,8 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                 }
                 // progress (src/render.rs:156-158 sends a snapshot every 800 ms): the queues advance evenly, so the number of the block just claimed
                 // is about the number of blocks handed out; the pollers store it (plain stores, last writer wins - an estimate, not a count)
-                if (poller && lane == 0 && blk < total_blocks) __hip_atomic_store(P.progress_word, P.progress_base + (single_rounds ? blk >> 3 : blk), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (poller && lane == 0 && blk < total_blocks)      // (+ the blocks of the empty tiles: done before the launch began)
+                    __hip_atomic_store(P.progress_word, P.progress_base + ((P.pix_slots >> 6) - active_tiles) * P.unit_count + (single_rounds ? blk >> 3 : blk), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 #ifdef RT_CLAIM_AHEAD
                 have_next = blk < total_blocks;
                 if (have_next && lane == 0) next_idx = atomicAdd(P.block_counter + queue * 16u, 1u);      // the NEXT block of this queue; looked at when this one is done
@@ -852,7 +858,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                     // Block numbering: first every unit of each tile whose rays hit something, tile after
                     // tile in cost order (so that the long blocks all start early), then the tiles that
                     // see only sky, unit by unit over the whole image.
-                    const uint32_t n_tiles = P.pix_slots >> 6;
+                    const uint32_t n_tiles = active_tiles;
                     const uint32_t heavy = P.tile_order ? P.tile_order[-1] : 0u, heavy_blocks = heavy * P.unit_count;
                     uint32_t tile_rank, unit_local;
                     if (blk < heavy_blocks) { tile_rank = blk / P.unit_count; unit_local = blk % P.unit_count; }
@@ -1430,14 +1436,16 @@ render_kernel(const DevSceneView S, const RenderParams P) {
 // With one-sample units the segment sums ((0 + c0) + c1) + ... are formed here, with the very
 // additions the render kernel performs for a whole-segment unit: both splits give the same bits.
 __global__ void fold_kernel(const float* partial, uint32_t unit_count, uint32_t unit_first, uint32_t unit_len, uint32_t npix, float* acc,
-                            uint32_t acc_pitch, uint32_t cw, uint32_t acc_x, uint32_t acc_y, int init_zero, uint32_t tiles_x, uint32_t pix_slots) {
+                            uint32_t acc_pitch, uint32_t cw, uint32_t acc_x, uint32_t acc_y, int init_zero, uint32_t tiles_x, uint32_t pix_slots, const uint32_t* tile_bin) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= npix) return;
     const uint32_t x = i % cw, y = i / cw;
     const uint32_t slot = ((y >> 3) * tiles_x + (x >> 3)) * 64u + (y & 7u) * 8u + (x & 7u);      // the render kernel's tile layout
     float* a = acc + ((uint64_t)(acc_y + y) * acc_pitch + acc_x + x) * 3;
     float r = init_zero ? 0.0f : a[0], g = init_zero ? 0.0f : a[1], b = init_zero ? 0.0f : a[2];
-    if (unit_len == RT_SAMPLE_SEGMENT) {             // units are whole segment sums
+    // an empty tile (classify_kernel) was never rendered: every one of its samples is the black sky's +0 and so is every segment sum, and x + 0 == x
+    if (tile_bin && (tile_bin[slot >> 6] & 0xffu) == RT_BIN_EMPTY) { }
+    else if (unit_len == RT_SAMPLE_SEGMENT) {             // units are whole segment sums
         for (uint32_t u = 0; u < unit_count; u++) {
             const float* p = partial + ((uint64_t)u * pix_slots + slot) * 3;
             r = r + p[0]; g = g + p[1]; b = b + p[2];
@@ -1491,8 +1499,50 @@ __global__ void finish_kernel(const float* acc, uint32_t src_pitch, uint32_t sx,
 // else, 3 only sky.  The order changes the schedule only, never a pixel.
 // Measured on weekend 1080p x 256 spp, per-rank time of the 8-rank strip partition:
 // 7.5-8.0 ms row-major, 6.2-6.5 ms ordered (ideal 6.1); Dreadnaught on one GPU 19.97 -> 19.08 ms.
-#define RT_COST_BINS 4u
+#define RT_COST_BINS 5u
+#define RT_GROUP_STRIDE (RT_COST_BINS + 1u)      /* group_counts: tiles per class, then the valid pixels of the group's empty tiles */
 #define RT_ORDER_GROUP 1024u      /* tiles per block of order_kernel; classify_kernel counts the classes per such group */
+
+// Packet test of one 8 x 8 tile against the scene's root box: true when EVERY camera ray of its pixels - every lens sample of every sample index - misses the box by a
+// margin far above the rounding of the per-ray test (slab() on S.tlas_min / S.tlas_max, what hit_closest starts with: bvh.rs:210-236 on the root, implementation.rs:92-118).
+// Under a black sky (color_sky_black, implementation.rs:517-519) such a sample is (0, 0, 0) whatever its lens draw, so the tile needs no ray at all; its camera rays are
+// still counted (a ray = one call of Scene::hit_closest, which the reference makes and which returns None at the root).
+// Geometry (Camera::get_ray, implementation.rs:482-491): a ray leaves o_s = origin + lens offset, |o_s - origin| <= r_l, and passes the focal-plane point T of its pixel at t = 1,
+// |T - Tc| <= r_t for the tile's centre point Tc; so the ray's point at parameter t lies within rho(t) = |1 - t| r_l + t r_t of C(t) = origin + t (Tc - origin), in every axis.
+// The tile is empty iff for no t >= 0 C(t) is inside the box grown by rho(t) + margin: rho is linear on [0, 1] and on [1, inf), so each piece is a slab test whose planes move
+// linearly with t - six half-line constraints p t >= q per piece.  Infinite or NaN boxes (planes) give constraints that never bind: such scenes are never culled.
+__device__ bool tile_misses_root(const DevSceneView& S, const RenderParams& P, uint32_t px0, uint32_t py0) {
+    const F3 org = ld3(S.cam_origin), hor = ld3(S.cam_horizontal), ver = ld3(S.cam_vertical);
+    const float uc = ((float)px0 + 3.5f) / (float)P.width, vc = ((float)P.height - ((float)py0 + 3.5f)) / (float)P.height;      // pixel_uv of the tile's centre
+    const F3 Tc = ld3(S.cam_llc) + (hor * uc) + (ver * vc);
+    const F3 b = Tc - org;
+    const float r_t = 4.0f * (length(hor) / (float)P.width + length(ver) / (float)P.height);      // (3.5 pixels each way: 4 leaves slack)
+    const float r_l = S.cam_lens_radius * (length(ld3(S.cam_u)) + length(ld3(S.cam_v))) * 1.001f;   // lens offsets are in [-R, R) along cam_u and cam_v
+    const float lo[3] = {S.tlas_min[0], S.tlas_min[1], S.tlas_min[2]}, hi[3] = {S.tlas_max[0], S.tlas_max[1], S.tlas_max[2]};
+    const float a3[3] = {org.x, org.y, org.z}, b3[3] = {b.x, b.y, b.z};
+    float scale = r_l + r_t, bmax = 0.0f;
+    for (int i = 0; i < 3; i++) { scale = fmaxf(scale, fmaxf(fmaxf(fabsf(lo[i]), fabsf(hi[i])), fabsf(a3[i]) + fabsf(b3[i]))); bmax = fmaxf(bmax, fabsf(b3[i])); }
+    const float margin = 1.0e-3f * scale;          // 10^4 x the relative rounding of the per-ray slab test
+    bool empty = true;
+    for (int piece = 0; piece < 2; piece++) {
+        // rho'(t) = alpha + beta t >= rho(t) + margin on the piece (the slope's own margin covers what grows with t: C(t)'s rounding, 1e-7 |b| t)
+        const float alpha = (piece == 0 ? r_l : -r_l) + margin;
+        const float beta = piece == 0 ? (r_t - r_l) : (r_l + r_t) * 1.001f + 1.0e-5f * bmax;
+        float t_lo = piece == 0 ? 0.0f : 1.0f, t_hi = piece == 0 ? 1.0f : RT_F32_MAX;
+        bool none = false;
+        for (int i = 0; i < 3; i++) {
+            // inside the grown slab i:  a + t b + rho' >= lo  and  a + t b - rho' <= hi
+            const float p[2] = {b3[i] + beta, beta - b3[i]}, q[2] = {lo[i] - a3[i] - alpha, a3[i] - hi[i] - alpha};
+            for (int c = 0; c < 2; c++) {
+                if (p[c] > 0.0f) { const float r = q[c] / p[c]; t_lo = fmaxf(t_lo, r - fabsf(r) * 1.0e-5f); }
+                else if (p[c] < 0.0f) { const float r = q[c] / p[c]; t_hi = fminf(t_hi, r + fabsf(r) * 1.0e-5f); }
+                else if (q[c] > 0.0f) none = true;
+            }
+        }
+        if (!(none || t_lo > t_hi)) empty = false;      // (a NaN anywhere: not provably empty)
+    }
+    return empty;
+}
 __global__ void __launch_bounds__(RT_BLOCK)
 classify_kernel(const DevSceneView S, const RenderParams P, uint32_t n_tiles, uint32_t* tile_bin, uint32_t* group_counts) {
     extern __shared__ uint32_t lds_stack[];
@@ -1505,9 +1555,15 @@ classify_kernel(const DevSceneView S, const RenderParams P, uint32_t n_tiles, ui
     const uint32_t x = (tl % P.tiles_x) * 8u + 2u * (k & 3u) + ((k >> 2) & 1u), y = (tl / P.tiles_x) * 8u + 2u * (k >> 2) + (k & 1u);
     uint32_t cls = 3u;
     float coc = 0.0f, hits = 0.0f;
-    if (live && x < P.cw && y < P.ch) {
-        const uint32_t px = P.col_n ? ((x >> 3) * P.col_n + P.col_r) * 8u + (x & 7u) : P.left + x;
-        const uint32_t py = P.strip_h ? P.strip_first_row + (y / P.strip_h) * P.strip_period_rows + (y % P.strip_h) : P.top + y;
+    const uint32_t px = P.col_n ? ((x >> 3) * P.col_n + P.col_r) * 8u + (x & 7u) : P.left + x;
+    const uint32_t py = P.strip_h ? P.strip_first_row + (y / P.strip_h) * P.strip_period_rows + (y % P.strip_h) : P.top + y;
+    // empty tiles (all 16 lanes of a tile find the same answer: px, py are those of its first pixel for k == 0, and the test is asked for that one)
+    const uint32_t tx0 = (tl % P.tiles_x) * 8u, ty0 = (tl / P.tiles_x) * 8u;
+    const bool empty = P.cull_empty && live &&
+                       tile_misses_root(S, P, P.col_n ? ((tx0 >> 3) * P.col_n + P.col_r) * 8u : P.left + tx0,
+                                        P.strip_h ? P.strip_first_row + (ty0 / P.strip_h) * P.strip_period_rows + (ty0 % P.strip_h) : P.top + ty0);
+    if (empty) cls = RT_BIN_EMPTY;
+    else if (live && x < P.cw && y < P.ch) {
         float pu, pv; F3 o, d;
         pixel_uv(P, px, py, pu, pv);
         gen_camera_ray(S, pu, pv, 0.0f, 0.0f, o, d);
@@ -1523,7 +1579,7 @@ classify_kernel(const DevSceneView S, const RenderParams P, uint32_t n_tiles, ui
         }
     }
     for (int off = 8; off > 0; off >>= 1) {
-        const uint32_t other = (uint32_t)__shfl_xor((int)cls, off, 64); cls = other < cls ? other : cls;
+        const uint32_t other = (uint32_t)__shfl_xor((int)cls, off, 64); cls = other < cls ? other : cls;      // (the 16 lanes of an empty tile all say so)
         coc += __shfl_xor(coc, off, 64); hits += __shfl_xor(hits, off, 64);
     }
     // Round shape of the tile (render_kernel): where the rays of a pixel spread over more than P.lens_coc_px pixels,
@@ -1536,7 +1592,13 @@ classify_kernel(const DevSceneView S, const RenderParams P, uint32_t n_tiles, ui
     for (uint32_t c = 0; c < RT_COST_BINS; c++) {
         const unsigned long long m = __ballot(live && k == 0u && cls == c);
         if (m != 0ull && (threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)m) - 1))
-            atomicAdd(group_counts + (tile / RT_ORDER_GROUP) * RT_COST_BINS + c, (uint32_t)__popcll(m));
+            atomicAdd(group_counts + (tile / RT_ORDER_GROUP) * RT_GROUP_STRIDE + c, (uint32_t)__popcll(m));
+    }
+    // the pixels of the chunk inside the group's empty tiles (their camera rays are counted by order_kernel): one add per wave
+    if (P.cull_empty) {
+        uint32_t npx = (live && k == 0u && cls == RT_BIN_EMPTY) ? (P.cw - tx0 < 8u ? P.cw - tx0 : 8u) * (P.ch - ty0 < 8u ? P.ch - ty0 : 8u) : 0u;
+        npx += (uint32_t)__shfl_xor((int)npx, 16, 64); npx += (uint32_t)__shfl_xor((int)npx, 32, 64);
+        if ((threadIdx.x & 63u) == 0u && npx) atomicAdd(group_counts + (tile / RT_ORDER_GROUP) * RT_GROUP_STRIDE + RT_COST_BINS, npx);
     }
 }
 
@@ -1547,7 +1609,7 @@ classify_kernel(const DevSceneView S, const RenderParams P, uint32_t n_tiles, ui
 // over 1024 partial counts ran on four threads: 65 us per launch whatever the share of the frame - a fixed cost that an 8-rank split of a
 // 10 ms frame pays in full.  This one: a few us.)
 __global__ void __launch_bounds__(RT_ORDER_GROUP)
-order_kernel(const uint32_t* tile_bin, uint32_t n_tiles, const uint32_t* group_counts, uint32_t* tile_order) {
+order_kernel(const uint32_t* tile_bin, uint32_t n_tiles, const uint32_t* group_counts, uint32_t* tile_order, unsigned long long* counters, uint32_t sample_count, uint32_t* culled_word) {
     __shared__ uint32_t wave_count[RT_ORDER_GROUP / 64u][RT_COST_BINS];
     __shared__ uint32_t group_base[RT_COST_BINS];
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6, g = blockIdx.x, n_groups = gridDim.x;
@@ -1560,7 +1622,7 @@ order_kernel(const uint32_t* tile_bin, uint32_t n_tiles, const uint32_t* group_c
 #pragma unroll
         for (uint32_t b = 0; b < RT_COST_BINS; b++) {
             uint32_t a = 0, c = 0;
-            for (uint32_t k = lane; k < n_groups; k += 64u) { const uint32_t v = group_counts[k * RT_COST_BINS + b]; a += v; c += k < g ? v : 0u; }
+            for (uint32_t k = lane; k < n_groups; k += 64u) { const uint32_t v = group_counts[k * RT_GROUP_STRIDE + b]; a += v; c += k < g ? v : 0u; }
             for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off, 64); c += __shfl_xor(c, off, 64); }
             total[b] = a; before[b] = c;
         }
@@ -1568,7 +1630,23 @@ order_kernel(const uint32_t* tile_bin, uint32_t n_tiles, const uint32_t* group_c
             uint32_t run = 0;
 #pragma unroll
             for (uint32_t b = 0; b < RT_COST_BINS; b++) { group_base[b] = run + before[b]; run += total[b]; }
-            if (g == 0u) tile_order[-1] = total[0] + total[1] + total[2];      // every tile that hits something: all classes but "sky only"
+            if (g == 0u) {
+                tile_order[-1] = total[0] + total[1] + total[2];      // every tile that hits something: all classes but "sky only" and "empty"
+                tile_order[-2] = total[0] + total[1] + total[2] + total[3];      // every tile that is handed out: all but the empty ones
+            }
+        }
+        if (g == 0u) {
+            // empty tiles: their samples are never rendered, but their camera rays were cast as far as the reference is concerned (hit_closest -> None at the root)
+            uint32_t px = 0;
+            for (uint32_t k = lane; k < n_groups; k += 64u) px += group_counts[k * RT_GROUP_STRIDE + RT_COST_BINS];
+            for (int off = 32; off > 0; off >>= 1) px += __shfl_xor(px, off, 64);
+            if (lane == 0u) {
+                if (counters && px) {
+                    atomicAdd(counters + 0, (unsigned long long)px * sample_count);      // primary
+                    atomicAdd(counters + 3, (unsigned long long)px * sample_count);      // samples
+                }
+                if (culled_word) __hip_atomic_store(culled_word, px, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
     }
     uint32_t rank = 0;
@@ -1838,6 +1916,7 @@ struct SceneOptions {
     int round_units = 8;            // RT_OPT_ROUND_UNITS
     float lens_coc_px = 3.0f;       // RT_OPT_LENS_COC_PX (with 8 x 8 lens cells: mesh_demo 4K x 1024 spp 16 871 / 16 819 / 16 732 / 16 484 / 16 000 Mrays/s at 2 / 3 / 4 / 6 / 8 px, weekend within 0.6 %)
     int kind_order = 0;             // RT_KIND_ORDER=1 in the RT_KIND_ORDER_EXPERIMENT build
+    int cull_empty_tiles = 1;       // RT_OPT_CULL_EMPTY_TILES: tiles whose camera rays all miss the root box under a black sky are not traced (same bits, same counters)
     uint32_t debug_stack_entries = 0;   // RT_OPT_DEBUG_STACK_ENTRIES: 0 = what the trees need
     uint32_t debug_rebuild_stack_limit = 0;   // RT_OPT_DEBUG_REBUILD_STACK_LIMIT: rt_scene_rebuild_tlas refuses trees that need more stack entries (0 = the LDS limit)
 };
@@ -1852,6 +1931,7 @@ struct RtScene {
     // [32] the progress word (written by the render kernel); the totals live on the host
     volatile uint32_t* cancel_host() const { return dev_error_host + 16; }
     volatile uint32_t* progress_host() const { return dev_error_host + 32; }
+    volatile uint32_t* culled_host() const { return dev_error_host + 48; }      // valid pixels of the empty tiles of the latest call (order_kernel)
     std::atomic<uint64_t> progress_total{0};        // blocks of the call in flight (all its launches)
     struct MultiContext* multi = nullptr;           // rt_render_frame_multi: streams, events and buffers, owned by the scene passed first
     std::mutex multi_frame_lock;
@@ -1995,7 +2075,7 @@ int validate_call(const RtScene* scene, const RtSettings* st, const RtRenderChun
 }
 
 // bytes of the tile-order scratch of a launch over n_tiles tiles (enqueue_accumulate)
-size_t order_buffer_bytes(size_t n_tiles) { return ((n_tiles + RT_ORDER_GROUP - 1) / RT_ORDER_GROUP) * RT_COST_BINS * 4 + n_tiles * 8 + 16; }
+size_t order_buffer_bytes(size_t n_tiles) { return ((n_tiles + RT_ORDER_GROUP - 1) / RT_ORDER_GROUP) * RT_GROUP_STRIDE * 4 + n_tiles * 8 + 16; }
 
 // Enqueue: accumulate the sum of clamped samples [first, first+count) of the chunk
 // into `acc` (float3 image with pitch acc_pitch, chunk origin at acc_x/acc_y).
@@ -2066,6 +2146,13 @@ int enqueue_accumulate(RtScene* scene, Workspace& ws, const RtSettings* st, cons
     }
     DevSceneView view = scene->view;
     if (opt.debug_stack_entries && opt.debug_stack_entries < view.stack_entries) view.stack_entries = opt.debug_stack_entries;      // (tests of RT_E_DEPTH)
+    // Empty tiles: a tile whose every camera ray misses the scene's root box (tile_misses_root) is all black sky - no block of it is handed out, fold_kernel takes its
+    // samples as the zeros they are, order_kernel counts its camera rays.  Only where a miss is (0, 0, 0) whatever the ray: a black sky and at least one ray per sample
+    // (:562-564: max_reflections 0 casts none); not for scenes whose boxes do not bound (loose_boxes).  Same bits, same counters (RT_OPT_CULL_EMPTY_TILES 0 traces them).
+    P.cull_empty = (opt.cull_empty_tiles && view.sky == RT_SKY_BLACK && !view.loose_boxes && st->max_reflections > 0u) ? 1u : 0u;
+    P.culled_word = scene->dev_error_dev + 48;
+    *scene->culled_host() = 0u;
+    const uint32_t* tile_bin_dev = nullptr;
     // expensive tiles first (whole-segment launches over enough tiles to have a tail worth hiding)
     const uint32_t n_tiles = pix_slots / 64;
     static const bool order_tiles = []() { const char* e = getenv("RT_TILE_ORDER"); return !e || atoi(e) != 0; }();
@@ -2073,12 +2160,14 @@ int enqueue_accumulate(RtScene* scene, Workspace& ws, const RtSettings* st, cons
         const uint32_t n_groups = (n_tiles + RT_ORDER_GROUP - 1u) / RT_ORDER_GROUP;
         if ((rc = ws.order.ensure(order_buffer_bytes(n_tiles)))) return rc;
         // layout: [group_counts: n_groups x 4][tile_bin: n_tiles][3 spare + the expensive-tile count = tile_order[-1]][tile_order: n_tiles]
-        uint32_t* group_counts = (uint32_t*)ws.order.p; uint32_t* tile_bin = group_counts + (size_t)n_groups * RT_COST_BINS; uint32_t* tile_order = tile_bin + n_tiles + 4;
-        HIP_TRY(hipMemsetAsync(group_counts, 0, (size_t)n_groups * RT_COST_BINS * 4, stream));
+        uint32_t* group_counts = (uint32_t*)ws.order.p; uint32_t* tile_bin = group_counts + (size_t)n_groups * RT_GROUP_STRIDE; uint32_t* tile_order = tile_bin + n_tiles + 4;
+        tile_bin_dev = tile_bin;
+        HIP_TRY(hipMemsetAsync(group_counts, 0, (size_t)n_groups * RT_GROUP_STRIDE * 4, stream));
         hipLaunchKernelGGL(classify_kernel, dim3((n_tiles * 16 + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), scene->stack_lds_bytes, stream, view, P,
                            n_tiles, tile_bin, group_counts);
         HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(order_kernel, dim3(n_groups), dim3(RT_ORDER_GROUP), 0, stream, (const uint32_t*)tile_bin, n_tiles, (const uint32_t*)group_counts, tile_order);
+        hipLaunchKernelGGL(order_kernel, dim3(n_groups), dim3(RT_ORDER_GROUP), 0, stream, (const uint32_t*)tile_bin, n_tiles, (const uint32_t*)group_counts, tile_order,
+                           P.cull_empty ? counters_dev : (unsigned long long*)nullptr, sample_count, P.cull_empty ? P.culled_word : (uint32_t*)nullptr);
         HIP_TRY(hipGetLastError());
         P.tile_order = tile_order;
     }
@@ -2182,7 +2271,7 @@ int enqueue_accumulate(RtScene* scene, Workspace& ws, const RtSettings* st, cons
             scene->profile_events.emplace_back(ev0, ev1);
         }
         hipLaunchKernelGGL(fold_kernel, dim3((npix + 255) / 256), dim3(256), 0, stream, (const float*)ws.partial.p, P.unit_count, P.unit_first, unit_len, npix, acc, acc_pitch,
-                           ch->width, acc_x, acc_y, (init_zero && b0 == 0) ? 1 : 0, tiles_x, pix_slots);
+                           ch->width, acc_x, acc_y, (init_zero && b0 == 0) ? 1 : 0, tiles_x, pix_slots, (P.tile_order && P.cull_empty) ? tile_bin_dev : (const uint32_t*)nullptr);
         HIP_TRY(hipGetLastError());
         P.progress_base += (uint32_t)((uint64_t)(pix_slots / 64) * P.unit_count);
     }
@@ -2269,7 +2358,7 @@ RtScene* rt_scene_create(const RtSceneDesc* desc, int device) {
     s->grid_blocks = prop.multiProcessorCount * per_cu;
     if (s->shared.init(false)) return fail();
     if (hipHostMalloc((void**)&s->dev_error_host, 256, hipHostMallocMapped) != hipSuccess) { s->dev_error_host = nullptr; set_error(RT_E_HIP, "hipHostMalloc (error word) failed"); return fail(); }
-    memset(s->dev_error_host, 0, 256);      // error word, cancel word, progress word: one cache line each
+    memset(s->dev_error_host, 0, 256);      // error word, cancel word, progress word, culled-pixels word: one cache line each
     if (hipHostGetDevicePointer((void**)&s->dev_error_dev, s->dev_error_host, 0) != hipSuccess) { set_error(RT_E_HIP, "hipHostGetDevicePointer failed"); return fail(); }
     // defaults of the options from the environment, read once
     if (const char* e = getenv("RT_LENS_STRATIFY")) s->opt.lens_stratify = atoi(e) != 0;
@@ -2277,6 +2366,7 @@ RtScene* rt_scene_create(const RtSceneDesc* desc, int device) {
     if (const char* e = getenv("RT_ROUND_UNITS")) s->opt.round_units = atoi(e);
     if (const char* e = getenv("RT_LENS_COC")) s->opt.lens_coc_px = (float)atof(e);
     if (const char* e = getenv("RT_KIND_ORDER")) s->opt.kind_order = atoi(e) != 0;
+    if (const char* e = getenv("RT_CULL_TILES")) s->opt.cull_empty_tiles = atoi(e) != 0;
     return s;
 }
 
@@ -2296,6 +2386,9 @@ int rt_scene_set_option(RtScene* scene, uint32_t option, double value) {
         case RT_OPT_LENS_COC_PX:
             if (!(value >= 0.0)) return set_error(RT_E_INVALID, "RT_OPT_LENS_COC_PX: a circle of confusion in pixels, >= 0");
             scene->opt.lens_coc_px = (float)value; return RT_OK;
+        case RT_OPT_CULL_EMPTY_TILES:
+            if (value != 0.0 && value != 1.0) return set_error(RT_E_INVALID, "RT_OPT_CULL_EMPTY_TILES: 0 or 1");
+            scene->opt.cull_empty_tiles = (int)value; return RT_OK;
         case RT_OPT_DEBUG_STACK_ENTRIES:
             if (!(value >= 0.0 && value <= 1024.0)) return set_error(RT_E_INVALID, "RT_OPT_DEBUG_STACK_ENTRIES: 0 (as built) .. 1024");
             scene->opt.debug_stack_entries = (uint32_t)value;
@@ -2871,6 +2964,13 @@ int rt_scene_cancel(RtScene* scene, int cancel) {
     if (!scene) return set_error(RT_E_INVALID, "null scene");
     if (scene->device == RT_DEVICE_HOST_ONLY || !scene->dev_error_host) return set_error(RT_E_NO_DEVICE, "scene was created host-only");
     __atomic_store_n((uint32_t*)scene->cancel_host(), cancel ? 1u : 0u, __ATOMIC_SEQ_CST);      // host-mapped: the waves see it at their next poll
+    return RT_OK;
+}
+
+int rt_scene_culled_pixels(const RtScene* scene, uint64_t* pixels) {
+    if (!scene || !pixels) return set_error(RT_E_INVALID, "null argument");
+    if (scene->device == RT_DEVICE_HOST_ONLY || !scene->dev_error_host) return set_error(RT_E_NO_DEVICE, "scene was created host-only");
+    *pixels = *scene->culled_host();
     return RT_OK;
 }
 

@@ -268,12 +268,12 @@ class Scene:
         return rc
 
     OPTIONS = {"lens_sampler": _ffi.RT_OPT_LENS_SAMPLER, "fine_split": _ffi.RT_OPT_FINE_SPLIT, "round_units": _ffi.RT_OPT_ROUND_UNITS,
-               "lens_coc_px": _ffi.RT_OPT_LENS_COC_PX, "debug_stack_entries": _ffi.RT_OPT_DEBUG_STACK_ENTRIES,
+               "lens_coc_px": _ffi.RT_OPT_LENS_COC_PX, "cull_empty_tiles": _ffi.RT_OPT_CULL_EMPTY_TILES, "debug_stack_entries": _ffi.RT_OPT_DEBUG_STACK_ENTRIES,
                "debug_rebuild_stack_limit": _ffi.RT_OPT_DEBUG_REBUILD_STACK_LIMIT}
 
     def set_option(self, name, value):
         """rt_scene_set_option: "lens_sampler" 0 = the reference's independent lens draws / 1 = stratified (default);
-        "fine_split" -1 / 0 / 1, "round_units" 1 / 2 / 4 / 8 and "lens_coc_px" only change the schedule."""
+        "fine_split" -1 / 0 / 1, "round_units" 1 / 2 / 4 / 8, "lens_coc_px" and "cull_empty_tiles" 0 / 1 only change the schedule."""
         self._check(self._lib.rt_scene_set_option(self._h, self.OPTIONS[name], float(value)))
 
     def update_transforms(self, builder, stream=None):
@@ -361,6 +361,12 @@ class Scene:
         done, total = C.c_uint64(), C.c_uint64()
         self._check(self._lib.rt_scene_progress(self._h, C.byref(done), C.byref(total)))
         return done.value, total.value
+
+    def culled_pixels(self):
+        """rt_scene_culled_pixels: pixels of the latest call that lay in tiles skipped by the empty-tile packet test."""
+        n = C.c_uint64()
+        self._check(self._lib.rt_scene_culled_pixels(self._h, C.byref(n)))
+        return n.value
 
     def profile_enable(self, enable=True):
         self._check(self._lib.rt_scene_profile_enable(self._h, 1 if enable else 0))
