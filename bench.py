@@ -207,8 +207,8 @@ def measure(workload, args, ctx, mode=None, reduce=None, steps=None, warmup=None
     kernel_ms, launches = scene.profile_read()       # HIP events around every render_kernel launch, on its stream
     scene.profile_enable(False)
 
-    # camera rays in EMPTY tiles (every camera ray of the tile misses the scene's root box under a black sky: one packet test per tile instead of 64 x spp ray tests,
-    # rt_hip.h RT_OPT_CULL_EMPTY_TILES): counted as the rays they are for the reference (hit_closest is called and misses at the root) and by the CPU leg, never traced here
+    # camera rays in EMPTY tiles (every camera ray of the tile misses every leaf box of the scene under a black sky: one packet test per tile - its beam walks the trees - instead of 64 x spp rays,
+    # rt_hip.h RT_OPT_CULL_EMPTY_TILES): counted as the rays they are for the reference (hit_closest is called and finds no candidate) and for the CPU leg, never traced here
     local_culled = scene.culled_pixels() * (spp if args.mode == "tiles" else s_count)     # per step, this rank
     cn = torch.cat([counters, torch.tensor([local_culled], dtype=torch.int64, device=dev)])
     local_rays = int(cn[:3].sum().item())          # this rank's rays: what its own kernel launches traced (+ its empty tiles' camera rays)
@@ -282,7 +282,8 @@ def oracle_legs(m, args, n_gpus, cpu_leg=True, cpu_seconds=None):
     kernel_s = m["kernel_ms"] / 1e3 / launches
     rays_per_launch = m["local_rays"] / launches           # rank 0's launches (N > 1: its share of the frame)
     tflops = flops_per_ray * rays_per_launch / kernel_s / 1e12
-    # the same without the camera rays of empty tiles, which the model prices (one box test + the sky) and the kernel never traces
+    # the same without the camera rays of empty tiles, which the model prices and the kernel never traces (priced here at their floor, one box test + the sky:
+    # those that pass inner boxes before they miss cost the model more, so frac_traced errs high, never low)
     culled_per_launch = m.get("local_culled", 0) * m["steps"] / launches
     tflops_traced = (flops_per_ray * rays_per_launch - culled_per_launch * (F_AABB + F_SHADE)) / kernel_s / 1e12
     # algorithmic HBM bytes of one launch: the scene once + one float3 segment sum per work item

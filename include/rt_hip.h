@@ -299,9 +299,11 @@ enum {
     RT_OPT_ROUND_UNITS = 3,
     /* circle of confusion (pixels, default 3) from which a tile is traced in rounds of one lens cell.  Schedule only. */
     RT_OPT_LENS_COC_PX = 4,
-    /* 1 (default): 8 x 8 tiles whose camera rays ALL miss the scene's root box - a packet test of the tile's rays, every lens sample of every
-     * pixel, with a margin far above the rounding of the per-ray test - are not traced under a black sky: their samples are the (0, 0, 0) that
-     * color_sky_black gives every such ray (implementation.rs:517-519), their camera rays are counted (hit_closest is called and misses at the root).
+    /* 1 (default): 8 x 8 tiles whose camera rays ALL miss every leaf box of the scene's trees - a packet test: the beam of the tile's rays,
+     * every lens sample of every pixel, walks the TLAS and the BLAS of the instances it meets, with a margin far above the rounding of the
+     * per-ray box test - are not traced under a black sky: such a ray has no candidate (bvh.rs:210-236), hit_closest returns None and the sample
+     * is color_sky_black's (0, 0, 0) (implementation.rs:517-519); their camera rays are counted (the reference casts them).  Not for scenes
+     * with rotation axes that are not of unit length, nor with max_reflections 0.
      * 0: every sample is traced.  Never changes a bit of the image or a counter (rt_scene_culled_pixels says how many pixels were skipped). */
     RT_OPT_CULL_EMPTY_TILES = 5,
     /* tests of RT_E_DEPTH: run the kernels with a traversal stack of this many entries (0 = what the trees
@@ -314,8 +316,8 @@ enum {
 int rt_scene_set_option(RtScene* scene, uint32_t option, double value);
 
 /* How many pixels of the latest render call on this scene lay in tiles that RT_OPT_CULL_EMPTY_TILES skipped (0 when the call's tiles
- * were not classified: small chunks, single-sample work items).  No reference counterpart: the reference tests every ray against the root
- * box (bvh.rs:210-236); this reports how much of that the packet test replaced.  Readable while the call runs (host-mapped word). */
+ * were not classified: small chunks, single-sample work items).  No reference counterpart: the reference walks its trees for every ray
+ * (bvh.rs:210-236); this reports how much of that the packet test replaced.  Readable while the call runs (host-mapped word). */
 int rt_scene_culled_pixels(const RtScene* scene, uint64_t* pixels);
 
 /* Replaces the whole `for p in chunk.iter_pixels() { cast_rays_into_scene(..);

@@ -1503,46 +1503,124 @@ __global__ void finish_kernel(const float* acc, uint32_t src_pitch, uint32_t sx,
 #define RT_GROUP_STRIDE (RT_COST_BINS + 1u)      /* group_counts: tiles per class, then the valid pixels of the group's empty tiles */
 #define RT_ORDER_GROUP 1024u      /* tiles per block of order_kernel; classify_kernel counts the classes per such group */
 
-// Packet test of one 8 x 8 tile against the scene's root box: true when EVERY camera ray of its pixels - every lens sample of every sample index - misses the box by a
-// margin far above the rounding of the per-ray test (slab() on S.tlas_min / S.tlas_max, what hit_closest starts with: bvh.rs:210-236 on the root, implementation.rs:92-118).
-// Under a black sky (color_sky_black, implementation.rs:517-519) such a sample is (0, 0, 0) whatever its lens draw, so the tile needs no ray at all; its camera rays are
-// still counted (a ray = one call of Scene::hit_closest, which the reference makes and which returns None at the root).
+// Empty tiles: a packet test of one 8 x 8 tile against the scene.  A tile is EMPTY when every camera ray of its pixels - every lens sample of every sample index - misses, by a
+// margin far above the rounding of the per-ray tests, the box of every leaf of the trees: the reference reports a candidate only for leaves whose box (and whose ancestors'
+// boxes) the ray passes (bvh.rs:210-236 with implementation.rs:92-118), so such a ray has no candidate, hit_closest returns None and the sample is the sky's colour.  Under a
+// black sky (color_sky_black, implementation.rs:517-519) that is (0, 0, 0) whatever the lens draw, so the tile needs no ray at all; its camera rays are still counted
+// (a ray = one call of Scene::hit_closest, which the reference makes).
 // Geometry (Camera::get_ray, implementation.rs:482-491): a ray leaves o_s = origin + lens offset, |o_s - origin| <= r_l, and passes the focal-plane point T of its pixel at t = 1,
-// |T - Tc| <= r_t for the tile's centre point Tc; so the ray's point at parameter t lies within rho(t) = |1 - t| r_l + t r_t of C(t) = origin + t (Tc - origin), in every axis.
-// The tile is empty iff for no t >= 0 C(t) is inside the box grown by rho(t) + margin: rho is linear on [0, 1] and on [1, inf), so each piece is a slab test whose planes move
-// linearly with t - six half-line constraints p t >= q per piece.  Infinite or NaN boxes (planes) give constraints that never bind: such scenes are never culled.
-__device__ bool tile_misses_root(const DevSceneView& S, const RenderParams& P, uint32_t px0, uint32_t py0) {
-    const F3 org = ld3(S.cam_origin), hor = ld3(S.cam_horizontal), ver = ld3(S.cam_vertical);
-    const float uc = ((float)px0 + 3.5f) / (float)P.width, vc = ((float)P.height - ((float)py0 + 3.5f)) / (float)P.height;      // pixel_uv of the tile's centre
-    const F3 Tc = ld3(S.cam_llc) + (hor * uc) + (ver * vc);
-    const F3 b = Tc - org;
-    const float r_t = 4.0f * (length(hor) / (float)P.width + length(ver) / (float)P.height);      // (3.5 pixels each way: 4 leaves slack)
-    const float r_l = S.cam_lens_radius * (length(ld3(S.cam_u)) + length(ld3(S.cam_v))) * 1.001f;   // lens offsets are in [-R, R) along cam_u and cam_v
-    const float lo[3] = {S.tlas_min[0], S.tlas_min[1], S.tlas_min[2]}, hi[3] = {S.tlas_max[0], S.tlas_max[1], S.tlas_max[2]};
-    const float a3[3] = {org.x, org.y, org.z}, b3[3] = {b.x, b.y, b.z};
-    float scale = r_l + r_t, bmax = 0.0f;
-    for (int i = 0; i < 3; i++) { scale = fmaxf(scale, fmaxf(fmaxf(fabsf(lo[i]), fabsf(hi[i])), fabsf(a3[i]) + fabsf(b3[i]))); bmax = fmaxf(bmax, fabsf(b3[i])); }
-    const float margin = 1.0e-3f * scale;          // 10^4 x the relative rounding of the per-ray slab test
-    bool empty = true;
+// |T - Tc| <= r_t for the tile's centre point Tc; so the ray's point at parameter t lies within rho(t) = |1 - t| r_l + t r_t of C(t) = origin + t (Tc - origin), in every axis:
+// the BEAM.  It can meet a box only if for some t >= 0 C(t) is inside the box grown by rho(t) + margin; rho is linear on [0, 1] and on [1, inf), so each piece is a slab test
+// whose planes move linearly with t - six half-line constraints p t >= q per piece.  Infinite or NaN boxes (planes) give constraints that never bind: never empty.
+// The beam walks the trees the render kernel walks (any box it misses prunes everything below: inner boxes contain their leaves' boxes); into a mesh instance it goes as
+// Entity::hit takes a ray there (ray_to_entity on the central ray: translations and unit-axis rotations keep distances, so the radii stand; scenes with other axes -
+// loose_boxes - are not culled), and the first leaf box it meets - a sphere's or plane's entity box, a triangle leaf - ends the walk: not empty.
+struct Beam { float a[3], b[3]; float r_l, r_t, scale, bmax; };      // C(t) = a + t b; scale: the largest coordinate in play (the margin is relative to it)
+
+__device__ __forceinline__ bool beam_meets_box(const Beam& B, const float lo[3], const float hi[3]) {
+    float scale = B.scale;
+    for (int i = 0; i < 3; i++) scale = fmaxf(scale, fmaxf(fabsf(lo[i]), fabsf(hi[i])));
+    const float margin = 2.5e-4f * scale;          // 10^3 x the relative rounding of the per-ray slab test and of the ray transform
     for (int piece = 0; piece < 2; piece++) {
-        // rho'(t) = alpha + beta t >= rho(t) + margin on the piece (the slope's own margin covers what grows with t: C(t)'s rounding, 1e-7 |b| t)
-        const float alpha = (piece == 0 ? r_l : -r_l) + margin;
-        const float beta = piece == 0 ? (r_t - r_l) : (r_l + r_t) * 1.001f + 1.0e-5f * bmax;
+        // rho'(t) = alpha + beta t >= rho(t) + margin on the piece (the slope's own margin covers what grows with t: the rounding of C(t), 1e-7 |b| t)
+        const float alpha = (piece == 0 ? B.r_l : -B.r_l) + margin;
+        const float beta = piece == 0 ? (B.r_t - B.r_l) : (B.r_l + B.r_t) * 1.001f + 1.0e-5f * B.bmax;
         float t_lo = piece == 0 ? 0.0f : 1.0f, t_hi = piece == 0 ? 1.0f : RT_F32_MAX;
         bool none = false;
         for (int i = 0; i < 3; i++) {
             // inside the grown slab i:  a + t b + rho' >= lo  and  a + t b - rho' <= hi
-            const float p[2] = {b3[i] + beta, beta - b3[i]}, q[2] = {lo[i] - a3[i] - alpha, a3[i] - hi[i] - alpha};
+            const float p[2] = {B.b[i] + beta, beta - B.b[i]}, q[2] = {lo[i] - B.a[i] - alpha, B.a[i] - hi[i] - alpha};
             for (int c = 0; c < 2; c++) {
                 if (p[c] > 0.0f) { const float r = q[c] / p[c]; t_lo = fmaxf(t_lo, r - fabsf(r) * 1.0e-5f); }
                 else if (p[c] < 0.0f) { const float r = q[c] / p[c]; t_hi = fminf(t_hi, r + fabsf(r) * 1.0e-5f); }
                 else if (q[c] > 0.0f) none = true;
             }
         }
-        if (!(none || t_lo > t_hi)) empty = false;      // (a NaN anywhere: not provably empty)
+        if (!(none || t_lo > t_hi)) return true;      // (a NaN anywhere: not provably missed)
     }
-    return empty;
+    return false;
 }
+
+__device__ __forceinline__ void beam_set_ray(Beam& B, F3 a, F3 b) {
+    B.a[0] = a.x; B.a[1] = a.y; B.a[2] = a.z; B.b[0] = b.x; B.b[1] = b.y; B.b[2] = b.z;
+    B.bmax = fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fabsf(b.z));
+    B.scale = fmaxf(B.scale, fmaxf(fmaxf(fabsf(a.x) + fabsf(b.x), fabsf(a.y) + fabsf(b.y)), fabsf(a.z) + fabsf(b.z)));      // (only ever grows: the margin of the world beam stands inside an instance)
+}
+
+// px0, py0: the tile's first pixel in the image.  `stack`: this lane's LDS column, as in trace().
+__device__ bool tile_is_empty(const DevSceneView& S, const RenderParams& P, uint32_t px0, uint32_t py0, uint32_t* stack, const uint32_t stack_cap) {
+    const F3 org = ld3(S.cam_origin), hor = ld3(S.cam_horizontal), ver = ld3(S.cam_vertical);
+    const float uc = ((float)px0 + 3.5f) / (float)P.width, vc = ((float)P.height - ((float)py0 + 3.5f)) / (float)P.height;      // pixel_uv of the tile's centre
+    const F3 Tc = ld3(S.cam_llc) + (hor * uc) + (ver * vc);
+    Beam W;
+    W.r_t = 4.0f * (length(hor) / (float)P.width + length(ver) / (float)P.height);      // (3.5 pixels each way: 4 leaves slack)
+    W.r_l = S.cam_lens_radius * (length(ld3(S.cam_u)) + length(ld3(S.cam_v))) * 1.001f;   // lens offsets are in [-R, R) along cam_u and cam_v
+    W.scale = W.r_l + W.r_t;
+    beam_set_ray(W, org, Tc - org);
+    if (!beam_meets_box(W, S.tlas_min, S.tlas_max)) return true;
+    Beam B = W;
+    uint32_t sp = 0, inst_sp = RT_NONE, cur = S.tlas_root_ref;
+    auto pop = [&]() -> uint32_t {
+        if (sp == inst_sp) { inst_sp = RT_NONE; B = W; }
+        if (sp == 0) return RT_NONE;
+        return stack[(--sp) * RT_BLOCK];
+    };
+    for (;;) {
+        while (cur < RT_REF_LEAF_BIT) {
+            const Word4* n = S.nodes[cur].w;
+            const Word4 a = ldw(n), b = ldw(n + 1), c = ldw(n + 2), r = ldw(n + 3);
+            const float llo[3] = {a.f[0], a.f[2], b.f[0]}, lhi[3] = {b.f[2], c.f[0], c.f[2]}, rlo[3] = {a.f[1], a.f[3], b.f[1]}, rhi[3] = {b.f[3], c.f[1], c.f[3]};      // (slab2's layout)
+            const bool ml = beam_meets_box(B, llo, lhi), mr = beam_meets_box(B, rlo, rhi);
+            if (ml && mr) {
+                if (sp >= stack_cap) return false;      // (never expected: the stack is sized from the trees; then simply not culled)
+                stack[(sp++) * RT_BLOCK] = r.u[1];
+                cur = r.u[0];
+            } else if (ml || mr) cur = ml ? r.u[0] : r.u[1];
+            else cur = pop();
+        }
+        if (cur == RT_NONE) return true;                // every subtree pruned
+        if (inst_sp != RT_NONE) return false;           // a triangle leaf whose box the beam meets
+        const uint32_t first = cur & RT_REF_FIRST_MASK, count = ((cur >> RT_REF_COUNT_SHIFT) & 7u) + 1u;
+        bool entered = false;
+        for (uint32_t k = 0; k < count && !entered; k++) {
+            const uint32_t ei = first + k;
+            const Word4 bl = ldw(S.ent_box + 2 * ei), bh = ldw(S.ent_box + 2 * ei + 1);
+            const float elo[3] = {bl.f[0], bl.f[1], bl.f[2]}, ehi[3] = {bh.f[0], bh.f[1], bh.f[2]};
+            if (!beam_meets_box(W, elo, ehi)) continue;      // the entity's own world box (Entity::calculate_origin_aabb)
+            const Word4* ew = S.entities[ei].w;
+            const Word4 e0 = ldw(ew), e1 = ldw(ew + 1);
+            if ((e1.u[0] & 0xff) != RT_HITABLE_MESH) return false;      // a sphere or a plane in the beam's way
+            F3 eo = org, ed = Tc - org;
+            ray_to_entity(S, e0, e1, eo, ed);
+            Beam E = W;
+            beam_set_ray(E, eo, ed);
+            const Word4* mw = S.meshes[e1.u[1]].w;
+            const Word4 m0 = ldw(mw), m1 = ldw(mw + 1), m2 = ldw(mw + 2);
+            const float mlo[3] = {m1.f[0], m1.f[1], m1.f[2]}, mhi[3] = {m1.f[3], m2.f[0], m2.f[1]};
+            if (!beam_meets_box(E, mlo, mhi)) continue;
+            if (m0.u[3] >= RT_REF_LEAF_BIT) return false;    // a mesh of one leaf (its box is the root box)
+            if (k + 1 < count) {
+                if (sp >= stack_cap) return false;
+                stack[(sp++) * RT_BLOCK] = RT_REF_LEAF_BIT | ((count - k - 2) << RT_REF_COUNT_SHIFT) | (ei + 1);
+            }
+            inst_sp = sp; B = E; cur = m0.u[3]; entered = true;
+        }
+        if (!entered) cur = pop();
+    }
+}
+
+// one thread per tile: RT_BIN_EMPTY, or 0xff = to be classified
+__global__ void __launch_bounds__(RT_BLOCK)
+empty_tiles_kernel(const DevSceneView S, const RenderParams P, uint32_t n_tiles, uint32_t* tile_bin) {
+    extern __shared__ uint32_t lds_stack[];
+    const uint32_t tile = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tile >= n_tiles) return;
+    const uint32_t tx0 = (tile % P.tiles_x) * 8u, ty0 = (tile / P.tiles_x) * 8u;
+    const uint32_t px0 = P.col_n ? ((tx0 >> 3) * P.col_n + P.col_r) * 8u : P.left + tx0;
+    const uint32_t py0 = P.strip_h ? P.strip_first_row + (ty0 / P.strip_h) * P.strip_period_rows + (ty0 % P.strip_h) : P.top + ty0;
+    tile_bin[tile] = tile_is_empty(S, P, px0, py0, lds_stack + threadIdx.x, S.stack_entries) ? RT_BIN_EMPTY : 0xffu;
+}
+
 __global__ void __launch_bounds__(RT_BLOCK)
 classify_kernel(const DevSceneView S, const RenderParams P, uint32_t n_tiles, uint32_t* tile_bin, uint32_t* group_counts) {
     extern __shared__ uint32_t lds_stack[];
@@ -1557,11 +1635,9 @@ classify_kernel(const DevSceneView S, const RenderParams P, uint32_t n_tiles, ui
     float coc = 0.0f, hits = 0.0f;
     const uint32_t px = P.col_n ? ((x >> 3) * P.col_n + P.col_r) * 8u + (x & 7u) : P.left + x;
     const uint32_t py = P.strip_h ? P.strip_first_row + (y / P.strip_h) * P.strip_period_rows + (y % P.strip_h) : P.top + y;
-    // empty tiles (all 16 lanes of a tile find the same answer: px, py are those of its first pixel for k == 0, and the test is asked for that one)
+    // empty tiles: found by empty_tiles_kernel (all 16 lanes of a tile read its answer before lane 0 overwrites it below)
     const uint32_t tx0 = (tl % P.tiles_x) * 8u, ty0 = (tl / P.tiles_x) * 8u;
-    const bool empty = P.cull_empty && live &&
-                       tile_misses_root(S, P, P.col_n ? ((tx0 >> 3) * P.col_n + P.col_r) * 8u : P.left + tx0,
-                                        P.strip_h ? P.strip_first_row + (ty0 / P.strip_h) * P.strip_period_rows + (ty0 % P.strip_h) : P.top + ty0);
+    const bool empty = P.cull_empty && live && tile_bin[tl] == RT_BIN_EMPTY;
     if (empty) cls = RT_BIN_EMPTY;
     else if (live && x < P.cw && y < P.ch) {
         float pu, pv; F3 o, d;
@@ -2163,6 +2239,10 @@ int enqueue_accumulate(RtScene* scene, Workspace& ws, const RtSettings* st, cons
         uint32_t* group_counts = (uint32_t*)ws.order.p; uint32_t* tile_bin = group_counts + (size_t)n_groups * RT_GROUP_STRIDE; uint32_t* tile_order = tile_bin + n_tiles + 4;
         tile_bin_dev = tile_bin;
         HIP_TRY(hipMemsetAsync(group_counts, 0, (size_t)n_groups * RT_GROUP_STRIDE * 4, stream));
+        if (P.cull_empty) {
+            hipLaunchKernelGGL(empty_tiles_kernel, dim3((n_tiles + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), scene->stack_lds_bytes, stream, view, P, n_tiles, tile_bin);
+            HIP_TRY(hipGetLastError());
+        }
         hipLaunchKernelGGL(classify_kernel, dim3((n_tiles * 16 + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), scene->stack_lds_bytes, stream, view, P,
                            n_tiles, tile_bin, group_counts);
         HIP_TRY(hipGetLastError());
