@@ -16,7 +16,7 @@ for w in ("weekend-1080p-256spp", "dreadnaught-1080p-128spp", "meshdemo-4k-64spp
         continue                                                              # (the full C4 frame has SQ / TA passes only, and not in every collection)
     pmc = json.load(open(os.path.join(out_dir, f"pmc_{w}.json")))
     line = json.loads(open(os.path.join(out_dir, f"bench_{w}.json")).read().strip().splitlines()[-1])
-    rays = sum(line["rays_per_step"].values()) * line["steps"] // max(line["roofline"]["launches"], 1)      # a frame beyond the segment-sum cap takes several launches
+    rays = sum(line["rays_per_step"][k] for k in ("primary", "secondary", "shadow")) * line["steps"] // max(line["roofline"]["launches"], 1)      # a frame beyond the segment-sum cap takes several launches
     lane_util = pmc["SQ_THREAD_CYCLES_VALU"] / (64.0 * pmc["SQ_ACTIVE_INST_VALU"])
     counters[w] = {"valu_flops_fp32_wave_instr": pmc["SQ_INSTS_VALU_FLOPS_FP32"], "lane_util": round(lane_util, 4), "rays_per_launch": rays,
                    "valu_insts": pmc["SQ_INSTS_VALU"], "source": f"profiles/{tag}_pmc_{w}.json"}
