@@ -302,7 +302,9 @@ enum {
     /* 1 (default): 8 x 8 tiles whose camera rays ALL miss every leaf box of the scene's trees - a packet test: the beam of the tile's rays,
      * every lens sample of every pixel, walks the TLAS and the BLAS of the instances it meets, with a margin far above the rounding of the
      * per-ray box test - are not traced under a black sky: such a ray has no candidate (bvh.rs:210-236), hit_closest returns None and the sample
-     * is color_sky_black's (0, 0, 0) (implementation.rs:517-519); their camera rays are counted (the reference casts them).  Not for scenes
+     * is color_sky_black's (0, 0, 0) (implementation.rs:517-519); their camera rays are counted (the reference casts them).  Under the day sky,
+     * whose colour depends on the ray (:502-515), such tiles are rendered sample by sample but their camera rays skip the walk (scenes without
+     * mesh instances only).  Not for scenes
      * with rotation axes that are not of unit length, nor with max_reflections 0.
      * 0: every sample is traced.  Never changes a bit of the image or a counter (rt_scene_culled_pixels says how many pixels were skipped). */
     RT_OPT_CULL_EMPTY_TILES = 5,
@@ -315,10 +317,13 @@ enum {
 };
 int rt_scene_set_option(RtScene* scene, uint32_t option, double value);
 
-/* How many pixels of the latest render call on this scene lay in tiles that RT_OPT_CULL_EMPTY_TILES skipped (0 when the call's tiles
- * were not classified: small chunks, single-sample work items).  No reference counterpart: the reference walks its trees for every ray
- * (bvh.rs:210-236); this reports how much of that the packet test replaced.  Readable while the call runs (host-mapped word). */
-int rt_scene_culled_pixels(const RtScene* scene, uint64_t* pixels);
+/* What RT_OPT_CULL_EMPTY_TILES did in the latest render call on this scene (both outputs nullable; 0 when the call's tiles were not
+ * classified: small chunks, single-sample work items):
+ *   left_out     : pixels in empty tiles under a black sky - never rendered, (0, 0, 0) by construction;
+ *   without_walk : pixels in empty tiles under a sky whose colour depends on the ray - rendered sample by sample, their camera rays skip the walk.
+ * No reference counterpart: the reference walks its trees for every ray (bvh.rs:210-236); this reports how much of that the packet test
+ * replaced.  Readable while the call runs (host-mapped words). */
+int rt_scene_culled_pixels(const RtScene* scene, uint64_t* left_out, uint64_t* without_walk);
 
 /* Replaces the whole `for p in chunk.iter_pixels() { cast_rays_into_scene(..);
  * put_pixel(v3_to_rgba(..)) }` loop of src/render.rs:148-159 for one chunk

@@ -285,7 +285,7 @@ extern "C" {
     pub fn rt_render_frame_multi_host(scenes: *const *mut RtScene, n_scenes: u32, settings: *const RtSettings, mode: u32, seed: u64, rgb_out: *mut f32, rgba_out: *mut u8, counters: *mut RtRayCounters) -> c_int;
     pub fn rt_scene_cancel(scene: *mut RtScene, cancel: c_int) -> c_int;
     pub fn rt_scene_progress(scene: *const RtScene, blocks_done: *mut u64, blocks_total: *mut u64) -> c_int;
-    pub fn rt_scene_culled_pixels(scene: *const RtScene, pixels: *mut u64) -> c_int;
+    pub fn rt_scene_culled_pixels(scene: *const RtScene, left_out: *mut u64, without_walk: *mut u64) -> c_int;
     pub fn rt_resolve_device(device: c_int, accum_dev: *const c_void, n_pixels: u64, samples_per_pixel: u32, rgb_dev: *mut c_void, rgba_dev: *mut c_void, stream: *mut c_void) -> c_int;
     pub fn rt_primary_hits(scene: *mut RtScene, settings: *const RtSettings, chunk: *const RtRenderChunk, t_out: *mut f32, normal_out: *mut f32, entity_out: *mut i32, tri_out: *mut i32) -> c_int;
     pub fn rt_create_render_chunks(width: u32, height: u32, count_x: u32, count_y: u32, out: *mut RtRenderChunk, capacity: u32) -> c_int;
@@ -396,11 +396,12 @@ impl GpuScene {
         Ok((done, total))
     }
 
-    /// Pixels of the latest call that lay in tiles skipped by the empty-tile packet test (`RT_OPT_CULL_EMPTY_TILES`).
-    pub fn culled_pixels(&self) -> Result<u64, GpuError> {
-        let mut n = 0u64;
-        check(unsafe { rt_scene_culled_pixels(self.handle, &mut n) })?;
-        Ok(n)
+    /// What the empty-tile packet test (`RT_OPT_CULL_EMPTY_TILES`) did in the latest call: (pixels left out under a black sky,
+    /// pixels rendered without a walk under a sky that depends on the ray).
+    pub fn culled_pixels(&self) -> Result<(u64, u64), GpuError> {
+        let (mut left_out, mut without_walk) = (0u64, 0u64);
+        check(unsafe { rt_scene_culled_pixels(self.handle, &mut left_out, &mut without_walk) })?;
+        Ok((left_out, without_walk))
     }
 
     /// A deforming mesh: new vertex positions for mesh `mesh_index` (same triangle count); its tree is rebuilt on the device and the

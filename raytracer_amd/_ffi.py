@@ -193,7 +193,7 @@ HIP_PROTOTYPES = {
                                              _P(RtRayCounters)]),
     "rt_scene_cancel": (C.c_int, [C.c_void_p, C.c_int]),
     "rt_scene_progress": (C.c_int, [C.c_void_p, _P(C.c_uint64), _P(C.c_uint64)]),
-    "rt_scene_culled_pixels": (C.c_int, [C.c_void_p, _P(C.c_uint64)]),
+    "rt_scene_culled_pixels": (C.c_int, [C.c_void_p, _P(C.c_uint64), _P(C.c_uint64)]),
 }
 
 SAMPLES_PROTOTYPES = {

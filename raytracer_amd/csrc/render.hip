@@ -612,6 +612,7 @@ __device__ __forceinline__ float dielectric_kr(F3 dir, F3 normal, float ref_inde
 // the render kernel
 // ===========================================================================
 struct Pending { F3 o, d, w; uint32_t limit, node; };
+#define RT_BIN_NOHIT 0x200u       /* tile_bin flag beside the class and 0x100 (rounds by lens cell): none of the tile's camera rays can meet the scene, but the sky's colour depends on the ray */
 #define RT_BIN_EMPTY 4u           /* cost class (classify_kernel) of a tile none of whose camera rays can meet the scene: sorted last, never handed out */
 
 struct RenderParams {
@@ -635,7 +636,8 @@ struct RenderParams {
     unsigned long long* counters;                   // RtRayCounters on the device (nullable)
     uint32_t* block_counter;                        // RT_QUEUES counters, 64 B apart (zeroed per launch): next unclaimed block of each queue
     const uint32_t* tile_order;                     // k-th tile to hand out, expensive ones first; [-1] = how many are expensive, [-2] = how many are handed out at all (the rest is empty, below); null = row-major
-    uint32_t cull_empty;                            // classify_kernel may find tiles EMPTY (every camera ray of the tile misses the root box, black sky): never handed out, their samples are zeros
+    uint32_t cull_empty;                            // 1: empty_tiles_kernel runs - tiles none of whose camera rays can meet anything; 2: ... and the sky is black: such tiles are never handed out, their samples are zeros
+                                                    // (1, a sky that depends on the ray: they are handed out flagged, and their camera rays skip the walk)
     uint32_t* culled_word;                          // host-mapped: valid pixels of the call's empty tiles (rt_scene_culled_pixels)
 #ifdef RT_PHASE_STATS
     unsigned long long* phase_stats;                // diagnostics build only: [phase][lane-iterations, wave-iterations]
@@ -753,6 +755,12 @@ render_kernel(const DevSceneView S, const RenderParams P) {
     uint32_t pxy = 0, s = RT_NONE;           // pixel (x | y << 16) and sample index of the lane's current round (RT_NONE: no sample)
     // the wave's current block (wave-uniform): tile, unit, rounds started
     uint32_t blk_tile = 0, blk_unit = 0, round_next = 0, blk_lens = 0;
+    // where the rays of the current block start their walk: the TLAS root - or nowhere, in a tile whose camera rays cannot meet anything (empty_tiles_kernel; a sky that is
+    // not black, so the tile is rendered): a camera ray that misses has no child and casts no shadow ray, so every ray of such a block is a camera ray
+    // (NOHIT: instantiations without mesh instances only - carrying it cost the mesh scenes 1 % (Dreadnaught 6.92 -> 7.00 ms, mesh_demo 107.0 -> 107.9 ms) and the sample
+    //  scenes with meshes have a black sky, under which empty tiles are left out altogether; the host does not flag tiles for the others)
+    constexpr bool NOHIT = !MESH;
+    uint32_t blk_root = S.tlas_root_ref;
 #ifdef RT_CLAIM_AHEAD      /* measurement only: the next block claimed while this one starts, so that the atomic's round trip is hidden - one more register through the walk:
                               weekend -0.8 %, Dreadnaught -1.5 %, mesh_demo -0.5 %, 900 instances -0.9 %, 400x225x16 -8 % (blocks held back by busy waves).  Not adopted. */
     uint32_t next_idx = 0; bool have_next = false;      // the block claimed ahead (lane 0 holds its number)
@@ -865,7 +873,8 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                     else { const uint32_t b = blk - heavy_blocks, rest = n_tiles - heavy; unit_local = b / rest; tile_rank = heavy + b % rest; }
                     blk_tile = P.tile_order ? P.tile_order[tile_rank] : tile_rank;      // bit 31: the tile's rounds go by lens cell
                     blk_lens = (DOF && P.lens_rounds) ? blk_tile >> 31 : 0u;
-                    blk_tile &= 0x7fffffffu;
+                    if (NOHIT) blk_root = ((blk_tile >> 30) & 1u) ? RT_NONE : S.tlas_root_ref;
+                    blk_tile &= 0x3fffffffu;
                     {
                         const uint32_t x0 = (blk_tile % P.tiles_x) * 8u, y0 = (blk_tile / P.tiles_x) * 8u;
                         blk_xy0 = x0 | (y0 << 16);
@@ -1183,7 +1192,7 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                 sp = 0; inst_sp = RT_NONE;
                 float e;
                 cur = slab(S.tlas_min[0], S.tlas_min[1], S.tlas_min[2], S.tlas_max[0], S.tlas_max[1], S.tlas_max[2], o, inv, t_min, best_t, e)
-                          ? S.tlas_root_ref : RT_NONE;
+                          ? (NOHIT ? blk_root : S.tlas_root_ref) : RT_NONE;      // (blk_root: a tile the packet test found clear of every leaf box has no candidate for any of its rays - hit_closest is None without a walk)
                 tracing = true;
                 if (ECACHE) ray_dd = dot(d, d);
             }
@@ -1609,7 +1618,7 @@ __device__ bool tile_is_empty(const DevSceneView& S, const RenderParams& P, uint
     }
 }
 
-// one thread per tile: RT_BIN_EMPTY, or 0xff = to be classified
+// one thread per tile: RT_BIN_EMPTY (black sky: nothing to render), 0xff | RT_BIN_NOHIT (no camera ray of the tile can hit: sky-only, and the render kernel need not walk), or 0xff = to be classified
 __global__ void __launch_bounds__(RT_BLOCK)
 empty_tiles_kernel(const DevSceneView S, const RenderParams P, uint32_t n_tiles, uint32_t* tile_bin) {
     extern __shared__ uint32_t lds_stack[];
@@ -1618,7 +1627,8 @@ empty_tiles_kernel(const DevSceneView S, const RenderParams P, uint32_t n_tiles,
     const uint32_t tx0 = (tile % P.tiles_x) * 8u, ty0 = (tile / P.tiles_x) * 8u;
     const uint32_t px0 = P.col_n ? ((tx0 >> 3) * P.col_n + P.col_r) * 8u : P.left + tx0;
     const uint32_t py0 = P.strip_h ? P.strip_first_row + (ty0 / P.strip_h) * P.strip_period_rows + (ty0 % P.strip_h) : P.top + ty0;
-    tile_bin[tile] = tile_is_empty(S, P, px0, py0, lds_stack + threadIdx.x, S.stack_entries) ? RT_BIN_EMPTY : 0xffu;
+    const bool empty = tile_is_empty(S, P, px0, py0, lds_stack + threadIdx.x, S.stack_entries);
+    tile_bin[tile] = !empty ? 0xffu : (P.cull_empty == 2u ? RT_BIN_EMPTY : (0xffu | RT_BIN_NOHIT));
 }
 
 __global__ void __launch_bounds__(RT_BLOCK)
@@ -1637,8 +1647,10 @@ classify_kernel(const DevSceneView S, const RenderParams P, uint32_t n_tiles, ui
     const uint32_t py = P.strip_h ? P.strip_first_row + (y / P.strip_h) * P.strip_period_rows + (y % P.strip_h) : P.top + y;
     // empty tiles: found by empty_tiles_kernel (all 16 lanes of a tile read its answer before lane 0 overwrites it below)
     const uint32_t tx0 = (tl % P.tiles_x) * 8u, ty0 = (tl / P.tiles_x) * 8u;
-    const bool empty = P.cull_empty && live && tile_bin[tl] == RT_BIN_EMPTY;
+    const uint32_t pre = (P.cull_empty && live) ? tile_bin[tl] : 0xffu;
+    const bool empty = pre == RT_BIN_EMPTY, nohit = (pre & RT_BIN_NOHIT) != 0u;
     if (empty) cls = RT_BIN_EMPTY;
+    else if (nohit) { }      // (sky only, by the packet test: no ray to trace here either)
     else if (live && x < P.cw && y < P.ch) {
         float pu, pv; F3 o, d;
         pixel_uv(P, px, py, pu, pv);
@@ -1661,7 +1673,7 @@ classify_kernel(const DevSceneView S, const RenderParams P, uint32_t n_tiles, ui
     // Round shape of the tile (render_kernel): where the rays of a pixel spread over more than P.lens_coc_px pixels,
     // rounds of one sample index (one lens cell) of 8 neighbouring pixels are more coherent than rounds of one pixel.
     const uint32_t by_lens = (hits > 0.0f && coc > P.lens_coc_px * hits) ? 0x100u : 0u;
-    if (live && k == 0u) tile_bin[tile] = cls | by_lens;
+    if (live && k == 0u) tile_bin[tile] = cls | by_lens | (nohit ? RT_BIN_NOHIT : 0u);
     // class counts of the tile's group, for order_kernel: the four tiles of a wave lie in one group (RT_ORDER_GROUP is a multiple of 4) and are usually of one class,
     // so one add per wave and class present (one add per TILE, 1 024 to the same address, made this kernel 100 us slower)
 #pragma unroll
@@ -1672,7 +1684,7 @@ classify_kernel(const DevSceneView S, const RenderParams P, uint32_t n_tiles, ui
     }
     // the pixels of the chunk inside the group's empty tiles (their camera rays are counted by order_kernel): one add per wave
     if (P.cull_empty) {
-        uint32_t npx = (live && k == 0u && cls == RT_BIN_EMPTY) ? (P.cw - tx0 < 8u ? P.cw - tx0 : 8u) * (P.ch - ty0 < 8u ? P.ch - ty0 : 8u) : 0u;
+        uint32_t npx = (live && k == 0u && (empty || nohit)) ? (P.cw - tx0 < 8u ? P.cw - tx0 : 8u) * (P.ch - ty0 < 8u ? P.ch - ty0 : 8u) : 0u;
         npx += (uint32_t)__shfl_xor((int)npx, 16, 64); npx += (uint32_t)__shfl_xor((int)npx, 32, 64);
         if ((threadIdx.x & 63u) == 0u && npx) atomicAdd(group_counts + (tile / RT_ORDER_GROUP) * RT_GROUP_STRIDE + RT_COST_BINS, npx);
     }
@@ -1685,7 +1697,8 @@ classify_kernel(const DevSceneView S, const RenderParams P, uint32_t n_tiles, ui
 // over 1024 partial counts ran on four threads: 65 us per launch whatever the share of the frame - a fixed cost that an 8-rank split of a
 // 10 ms frame pays in full.  This one: a few us.)
 __global__ void __launch_bounds__(RT_ORDER_GROUP)
-order_kernel(const uint32_t* tile_bin, uint32_t n_tiles, const uint32_t* group_counts, uint32_t* tile_order, unsigned long long* counters, uint32_t sample_count, uint32_t* culled_word) {
+order_kernel(const uint32_t* tile_bin, uint32_t n_tiles, const uint32_t* group_counts, uint32_t* tile_order, unsigned long long* counters, uint32_t sample_count, uint32_t* culled_word,
+             uint32_t cull_mode) {
     __shared__ uint32_t wave_count[RT_ORDER_GROUP / 64u][RT_COST_BINS];
     __shared__ uint32_t group_base[RT_COST_BINS];
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6, g = blockIdx.x, n_groups = gridDim.x;
@@ -1717,11 +1730,11 @@ order_kernel(const uint32_t* tile_bin, uint32_t n_tiles, const uint32_t* group_c
             for (uint32_t k = lane; k < n_groups; k += 64u) px += group_counts[k * RT_GROUP_STRIDE + RT_COST_BINS];
             for (int off = 32; off > 0; off >>= 1) px += __shfl_xor(px, off, 64);
             if (lane == 0u) {
-                if (counters && px) {
+                if (cull_mode == 2u && counters && px) {      // (under another sky the tiles are rendered and count their own rays)
                     atomicAdd(counters + 0, (unsigned long long)px * sample_count);      // primary
                     atomicAdd(counters + 3, (unsigned long long)px * sample_count);      // samples
                 }
-                if (culled_word) __hip_atomic_store(culled_word, px, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (culled_word && cull_mode) __hip_atomic_store(culled_word + (cull_mode == 2u ? 0 : 1), px, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
     }
@@ -1736,7 +1749,7 @@ order_kernel(const uint32_t* tile_bin, uint32_t n_tiles, const uint32_t* group_c
     if (!live) return;
     uint32_t pos = group_base[cls] + rank;
     for (uint32_t w = 0; w < wave; w++) pos += wave_count[w][cls];
-    tile_order[pos] = i | ((bin >> 8) << 31);      // bit 31: rounds by lens cell
+    tile_order[pos] = i | (((bin >> 8) & 1u) << 31) | (((bin >> 9) & 1u) << 30);      // bit 31: rounds by lens cell; bit 30: no camera ray of the tile can hit anything
 }
 
 __global__ void __launch_bounds__(RT_BLOCK)
@@ -2007,7 +2020,7 @@ struct RtScene {
     // [32] the progress word (written by the render kernel); the totals live on the host
     volatile uint32_t* cancel_host() const { return dev_error_host + 16; }
     volatile uint32_t* progress_host() const { return dev_error_host + 32; }
-    volatile uint32_t* culled_host() const { return dev_error_host + 48; }      // valid pixels of the empty tiles of the latest call (order_kernel)
+    volatile uint32_t* culled_host() const { return dev_error_host + 48; }      // [0] pixels of the latest call in empty tiles that were left out (black sky), [1] in tiles rendered without a walk (order_kernel)
     std::atomic<uint64_t> progress_total{0};        // blocks of the call in flight (all its launches)
     struct MultiContext* multi = nullptr;           // rt_render_frame_multi: streams, events and buffers, owned by the scene passed first
     std::mutex multi_frame_lock;
@@ -2225,9 +2238,9 @@ int enqueue_accumulate(RtScene* scene, Workspace& ws, const RtSettings* st, cons
     // Empty tiles: a tile whose every camera ray misses the scene's root box (tile_misses_root) is all black sky - no block of it is handed out, fold_kernel takes its
     // samples as the zeros they are, order_kernel counts its camera rays.  Only where a miss is (0, 0, 0) whatever the ray: a black sky and at least one ray per sample
     // (:562-564: max_reflections 0 casts none); not for scenes whose boxes do not bound (loose_boxes).  Same bits, same counters (RT_OPT_CULL_EMPTY_TILES 0 traces them).
-    P.cull_empty = (opt.cull_empty_tiles && view.sky == RT_SKY_BLACK && !view.loose_boxes && st->max_reflections > 0u) ? 1u : 0u;
+    P.cull_empty = (opt.cull_empty_tiles && !view.loose_boxes && st->max_reflections > 0u) ? (view.sky == RT_SKY_BLACK ? 2u : (view.mesh_entities ? 0u : 1u)) : 0u;      // (1: render_kernel's NOHIT)
     P.culled_word = scene->dev_error_dev + 48;
-    *scene->culled_host() = 0u;
+    scene->culled_host()[0] = 0u; scene->culled_host()[1] = 0u;
     const uint32_t* tile_bin_dev = nullptr;
     // expensive tiles first (whole-segment launches over enough tiles to have a tail worth hiding)
     const uint32_t n_tiles = pix_slots / 64;
@@ -2247,7 +2260,7 @@ int enqueue_accumulate(RtScene* scene, Workspace& ws, const RtSettings* st, cons
                            n_tiles, tile_bin, group_counts);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(order_kernel, dim3(n_groups), dim3(RT_ORDER_GROUP), 0, stream, (const uint32_t*)tile_bin, n_tiles, (const uint32_t*)group_counts, tile_order,
-                           P.cull_empty ? counters_dev : (unsigned long long*)nullptr, sample_count, P.cull_empty ? P.culled_word : (uint32_t*)nullptr);
+                           counters_dev, sample_count, P.culled_word, P.cull_empty);
         HIP_TRY(hipGetLastError());
         P.tile_order = tile_order;
     }
@@ -2351,7 +2364,7 @@ int enqueue_accumulate(RtScene* scene, Workspace& ws, const RtSettings* st, cons
             scene->profile_events.emplace_back(ev0, ev1);
         }
         hipLaunchKernelGGL(fold_kernel, dim3((npix + 255) / 256), dim3(256), 0, stream, (const float*)ws.partial.p, P.unit_count, P.unit_first, unit_len, npix, acc, acc_pitch,
-                           ch->width, acc_x, acc_y, (init_zero && b0 == 0) ? 1 : 0, tiles_x, pix_slots, (P.tile_order && P.cull_empty) ? tile_bin_dev : (const uint32_t*)nullptr);
+                           ch->width, acc_x, acc_y, (init_zero && b0 == 0) ? 1 : 0, tiles_x, pix_slots, (P.tile_order && P.cull_empty == 2u) ? tile_bin_dev : (const uint32_t*)nullptr);
         HIP_TRY(hipGetLastError());
         P.progress_base += (uint32_t)((uint64_t)(pix_slots / 64) * P.unit_count);
     }
@@ -3047,10 +3060,11 @@ int rt_scene_cancel(RtScene* scene, int cancel) {
     return RT_OK;
 }
 
-int rt_scene_culled_pixels(const RtScene* scene, uint64_t* pixels) {
-    if (!scene || !pixels) return set_error(RT_E_INVALID, "null argument");
+int rt_scene_culled_pixels(const RtScene* scene, uint64_t* left_out, uint64_t* without_walk) {
+    if (!scene) return set_error(RT_E_INVALID, "null scene");
     if (scene->device == RT_DEVICE_HOST_ONLY || !scene->dev_error_host) return set_error(RT_E_NO_DEVICE, "scene was created host-only");
-    *pixels = *scene->culled_host();
+    if (left_out) *left_out = scene->culled_host()[0];
+    if (without_walk) *without_walk = scene->culled_host()[1];
     return RT_OK;
 }
 

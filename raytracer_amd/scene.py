@@ -362,11 +362,12 @@ class Scene:
         self._check(self._lib.rt_scene_progress(self._h, C.byref(done), C.byref(total)))
         return done.value, total.value
 
-    def culled_pixels(self):
-        """rt_scene_culled_pixels: pixels of the latest call that lay in tiles skipped by the empty-tile packet test."""
-        n = C.c_uint64()
-        self._check(self._lib.rt_scene_culled_pixels(self._h, C.byref(n)))
-        return n.value
+    def culled_pixels(self, both=False):
+        """rt_scene_culled_pixels: pixels of the latest call in empty tiles that were left out (black sky); both=True: also those rendered
+        without a walk (a sky that depends on the ray), as a pair."""
+        a, b = C.c_uint64(), C.c_uint64()
+        self._check(self._lib.rt_scene_culled_pixels(self._h, C.byref(a), C.byref(b)))
+        return (a.value, b.value) if both else a.value
 
     def profile_enable(self, enable=True):
         self._check(self._lib.rt_scene_profile_enable(self._h, 1 if enable else 0))

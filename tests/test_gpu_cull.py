@@ -51,7 +51,7 @@ def test_sample_scenes_under_a_black_sky(name, params):
     scene.close()
 
 
-def lone_objects(seed, w, h):
+def lone_objects(seed, w, h, sky=1, meshes=True):
     """A few spheres and meshes (no planes: their boxes are infinite) under a black sky, seen by a random camera - far, near, INSIDE the root box,
     wide and narrow, pinhole to a lens as large as the scene."""
     r = np.random.default_rng(seed)
@@ -63,7 +63,7 @@ def lone_objects(seed, w, h):
     to = r.uniform(-1, 1, 3) * float(r.choice([0.5, 4.0, 15.0]))                              # at the objects, or past them
     lens = float(r.choice([0.0, 0.05, 0.5, 3.0]))
     cam = camera_new(tuple(eye), tuple(to), float(r.choice([15.0, 50.0, 110.0])), w / h, lens, float(r.uniform(1.0, 30.0)))
-    b = SceneBuilder(cam, 1)                                                                   # RT_SKY_BLACK
+    b = SceneBuilder(cam, sky)                                                                 # 1: RT_SKY_BLACK, 0: RT_SKY_DAY
     mats = [b.add_lambertian(float(r.uniform(0.0, 0.5))), b.add_specular(0.8, 0.1), b.add_dielectric(0.6, 0.2, 1.5)]
     tex = b.add_color_texture((0.7, 0.6, 0.5))
     verts = r.uniform(-1, 1, (12, 3)).astype(np.float32)
@@ -71,7 +71,7 @@ def lone_objects(seed, w, h):
     for k in range(int(r.integers(1, 7))):
         tr = [tuple(r.uniform(-1, 1, 3) * (3, 1, 3) + (0, 1, 0))]
         ro = [((0.0, 1.0, 0.0), float(r.uniform(-3, 3)))] if r.random() < 0.5 else []
-        if r.random() < 0.6:
+        if r.random() < 0.6 or not meshes:
             b.add_sphere_entity(float(r.uniform(0.2, 1.0)), mats[int(r.integers(0, 3))], tex, translations=tr, rotations=ro, id=k)
         else:
             b.add_mesh_entity(mesh, mats[int(r.integers(0, 3))], tex, translations=tr, rotations=ro, id=k)
@@ -88,6 +88,45 @@ def test_random_cameras_and_lenses(seed):
     spp = [64, 16, 9][seed % 3]                                      # 64: the 8 x 8 lens cells reach into every corner of the lens square
     st = RenderSettings(w, h, 3, spp)
     on, off = render_both(scene, st, RenderChunk(0, 0, w, h), seed=seed)
+    assert_same(on, off)
+    scene.close()
+
+
+@pytest.mark.parametrize("seed", range(32))
+def test_tiles_without_a_hit_under_a_day_sky(seed):
+    """A sky whose colour depends on the ray (color_sky_day, implementation.rs:502-515): tiles whose beam is clear of every leaf box are still rendered - lens draw,
+    camera ray, sky colour per sample - but their camera rays skip the walk (render.hip: blk_nohit).  Same bits, same counters as with the option off."""
+    w, h = 200 + 8 * (seed % 5) + (seed % 3), 136 + (seed % 7)
+    scene = Scene(lone_objects(5000 + seed, w, h, sky=0, meshes=False), 0)
+    scene.set_option("fine_split", 0)
+    st = RenderSettings(w, h, 3, [64, 16, 9][seed % 3])
+    on, off = render_both(scene, st, RenderChunk(0, 0, w, h), seed=seed)
+    assert_same(on, off)
+    assert on[3] == 0                       # (nothing is left out under a day sky)
+    scene.close()
+
+
+def test_a_good_share_of_the_day_sky_cases_skips_walks():
+    n = 0
+    for seed in range(32):
+        w, h = 200, 136
+        scene = Scene(lone_objects(5000 + seed, w, h, sky=0, meshes=False), 0)
+        scene.set_option("fine_split", 0)
+        scene.render_chunk(RenderSettings(w, h, 1, 8), RenderChunk(0, 0, w, h), want_rgba=False)
+        left_out, without_walk = scene.culled_pixels(both=True)
+        assert left_out == 0
+        n += without_walk > 0
+        scene.close()
+    print(f"{n} of 32 day-sky cases have tiles rendered without a walk")
+    assert n >= 10
+
+
+@pytest.mark.parametrize("name", ["Random Spheres", "Simple", "Mesh", "Capsule"])
+def test_sample_scenes_with_the_option_on_and_off(name):
+    w, h = 384, 216
+    scene = Scene(SceneBuilder.sample(name, CameraConfiguration(w, h, lens_radius=0.1)), 0)
+    scene.set_option("fine_split", 0)
+    on, off = render_both(scene, RenderSettings(w, h, 5, 16), RenderChunk(0, 0, w, h))
     assert_same(on, off)
     scene.close()
 

@@ -1,4 +1,4 @@
-"""One-off sweep behind tests/test_gpu_cull.py: N random scenes under a black sky (spheres and mesh instances under stacked translations and rotations about
+"""One-off sweep behind tests/test_gpu_cull.py: N random scenes under a black or a day sky (spheres and mesh instances under stacked translations and rotations about
 random UNIT axes, random cameras from inside the scene to far away, pinhole to huge lenses, random image sizes and chunks): the frame with the empty-tile
 packet test on must equal the frame with it off bit for bit, counters included.   usage: python tools/cull_sweep.py [n_cases] [first_seed]"""
 import os, sys
@@ -20,7 +20,8 @@ for case in range(n_cases):
     lens = size * float(r.choice([0.0, 0.01, 0.2, 2.0]))
     focus = float(np.linalg.norm(eye - to)) * float(r.choice([0.1, 1.0, 4.0])) + 1e-3 * size
     cam = camera_new(tuple(eye), tuple(to), float(r.choice([5.0, 30.0, 70.0, 140.0])), w / h, lens, focus)
-    b = SceneBuilder(cam, 1)
+    b = SceneBuilder(cam, int(r.random() < 0.6))             # black sky: empty tiles are left out; day sky: their camera rays skip the walk
+    meshless = r.random() < 0.4                                  # (a day sky skips walks in scenes without mesh instances only)
     mats = [b.add_lambertian(float(r.uniform(0.0, 0.5))), b.add_specular(0.8, 0.1), b.add_dielectric(0.6, 0.2, 1.5)]
     tex = b.add_color_texture((0.7, 0.6, 0.5))
     meshes = []
@@ -35,7 +36,7 @@ for case in range(n_cases):
             axis = r.normal(size=3); axis /= np.linalg.norm(axis)
             axis = [(1.0, 0.0, 0.0), (0.0, 1.0, 0.0), (0.0, 0.0, 1.0), tuple(float(x) for x in axis.astype(np.float32))][int(r.integers(0, 4))]
             ro.append((axis, float(r.uniform(-3.2, 3.2))))
-        if r.random() < 0.5:
+        if r.random() < 0.5 or meshless:
             b.add_sphere_entity(float(r.uniform(0.05, 0.6)) * size, mats[int(r.integers(0, 3))], tex, translations=tr, rotations=ro, id=k)
         else:
             b.add_mesh_entity(meshes[int(r.integers(0, len(meshes)))], mats[int(r.integers(0, 3))], tex, translations=tr, rotations=ro, id=k)
