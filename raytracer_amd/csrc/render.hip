@@ -612,6 +612,7 @@ __device__ __forceinline__ float dielectric_kr(F3 dir, F3 normal, float ref_inde
 // the render kernel
 // ===========================================================================
 struct Pending { F3 o, d, w; uint32_t limit, node; };
+#define RT_SINGLE_ROUNDS_BELOW 6u /* blocks per resident wave below which a launch hands out single rounds (Dreadnaught: 10 per wave -1.8 %, 5 per wave +6.5 %, 2.5 per wave +27 %) */
 #define RT_BIN_NOHIT 0x200u       /* tile_bin flag beside the class and 0x100 (rounds by lens cell): none of the tile's camera rays can meet the scene, but the sky's colour depends on the ray */
 #define RT_BIN_EMPTY 4u           /* cost class (classify_kernel) of a tile none of whose camera rays can meet the scene: sorted last, never handed out */
 
@@ -643,7 +644,7 @@ struct RenderParams {
     unsigned long long* phase_stats;                // diagnostics build only: [phase][lane-iterations, wave-iterations]
 #endif
     uint32_t strip_h, strip_period_rows, strip_first_row;   // strip_h != 0: local row y -> image row (interleaved strips)
-    uint32_t single_rounds;                         // RT_SINGLE_ROUNDS_EXPERIMENT build: 1 = a claim covers one round of a block (whole-segment units only)
+    uint32_t single_rounds;                         // launches of fewer blocks than this hand out single ROUNDS of a block (whole-segment units, instantiations without depth of field); 0 = never
     uint32_t col_n, col_r;                          // col_n != 0: the chunk is the packed tile columns col_r, col_r + col_n, ... of the frame (local tile column j -> image tile column j * col_n + col_r)
 };
 
@@ -817,15 +818,17 @@ render_kernel(const DevSceneView S, const RenderParams P) {
                 // (same-address atomics serialise in L2: one counter cost 3 % of the headline frame and
                 // half of a single-sample launch).  A wave starts at its own counter and moves on to the
                 // next one when that is exhausted, so the hand-out order stays "expensive first".
-                // RT_SINGLE_ROUNDS_EXPERIMENT (`make singlerounds`, RT_SINGLE_ROUNDS=1): a claim is ONE round of a block (64 samples instead of 512), against the tail of launches
-                // with few blocks per resident wave (one rank's share of an N-GPU frame).  Claims 8b .. 8b + 7 are the rounds of block b; the eight rounds of a LENS-CELL block are
-                // chained through one output slot, so its claim 8b runs all of them and 8b + 1 .. 7 are empty.  Same pixels (176 parity tests); measured a loss everywhere - a claim is an
-                // atomic round trip, a dependent read of the tile order and four integer divisions: full frames -25 % (weekend), -17 % (Dreadnaught), -7 % (mesh_demo), and the slowest
-                // of 8 ranks no earlier: the expensive tiles of mesh_demo are lens-cell blocks, which stay one claim.
+                // Single-round claims: a claim is ONE round of a block (64 samples instead of 512), against the tail of launches with few blocks per resident wave (one rank's
+                // share of an N-GPU frame, a chunk of the host's chunk grid).  Claims 8b .. 8b + 7 are the rounds of block b.  Same pixels.  A claim is an atomic round trip, a
+                // dependent read of the tile order and four integer divisions: on full frames it loses (round 3, every claim of every launch single: weekend -25 %, Dreadnaught -17 %
+                // with its sky blocks, -4.5 % without them, mesh_demo -7 %), so only launches that hand out fewer than P.single_rounds blocks (about 6 per resident wave; the kernel
+                // knows how many tiles are handed out at all, the host does not) - Dreadnaught's share of 8 ranks 1.57 -> 1.23 ms, of 4 ranks 2.23 -> 2.09 ms.  Not in the instantiations
+                // with depth of field: the eight rounds of a LENS-CELL block are chained through one output slot and stay one claim, and mesh_demo's expensive tiles are such blocks
+                // (its slowest of 8 ranks: no earlier).  (`make singlerounds` compiles it into every instantiation; RT_SINGLE_ROUNDS=1 / 0 forces / forbids it.)
 #ifdef RT_SINGLE_ROUNDS_EXPERIMENT
-                const uint32_t single_rounds = P.single_rounds;
+                const uint32_t single_rounds = (total_items >> 6) < P.single_rounds ? 1u : 0u;
 #else
-                constexpr uint32_t single_rounds = 0u;
+                const uint32_t single_rounds = (!DOF && (total_items >> 6) < P.single_rounds) ? 1u : 0u;
 #endif
                 const uint32_t total_blocks = single_rounds ? (total_items >> 6) << 3 : total_items >> 6;          // pix_slots is a multiple of 64
                 uint32_t blk = total_blocks;
@@ -2280,8 +2283,10 @@ int enqueue_accumulate(RtScene* scene, Workspace& ws, const RtSettings* st, cons
             while (!fine && P.round_units_shift < max_shift && P.unit_count % (2u << P.round_units_shift) == 0) P.round_units_shift++;
             // (without the stratified sampler the samples of one index do not share a lens cell: nothing to gain from that round shape)
             if (P.round_units_shift != 3u || !P.lens_stratify) P.lens_rounds = 0u;
-            static const bool single = []() { const char* e = getenv("RT_SINGLE_ROUNDS"); return e && atoi(e) != 0; }();      // (only the RT_SINGLE_ROUNDS_EXPERIMENT build looks at it)
-            P.single_rounds = (single && !fine && unit_len == RT_SAMPLE_SEGMENT) ? 1u : 0u;
+            // single-round claims for launches of few blocks per resident wave (render_kernel: block claims); RT_SINGLE_ROUNDS=1 always (where compiled in), 0 never
+            static const int single = []() { const char* e = getenv("RT_SINGLE_ROUNDS"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
+            const uint32_t below = single < 0 ? (uint32_t)scene->grid_blocks * (RT_BLOCK / 64u) * RT_SINGLE_ROUNDS_BELOW : (single ? 0xffffffffu : 0u);
+            P.single_rounds = (!fine && unit_len == RT_SAMPLE_SEGMENT) ? below : 0u;
         }
         const uint64_t items = (uint64_t)P.pix_slots * P.unit_count;
         uint64_t blocks = (items + RT_BLOCK - 1) / RT_BLOCK;
