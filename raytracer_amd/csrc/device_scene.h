@@ -119,6 +119,8 @@ struct DevSceneView {
     const int32_t* tex_set_entries;
     const float* texels;          // 3 floats per texel
     const DevLight* lights;
+    // (behind everything the render kernel reads: a new field in the middle moves its kernel arguments, and with them its code - weekend -0.7 %)
+    uint32_t uniform_cost_class;  // every material of the scene gives a hit the same cost class (classify_kernel: 0 dielectric, 1 reflective, 2 other): that class; 0xff: they differ
 };
 
 #endif

@@ -722,6 +722,14 @@ int build_flat_scene(const RtSceneDesc* d, FlatScene& out, std::string& err) {
     // scatter yields a refraction, i.e. a MatDielectric; without any, the first hit found decides.
     v.shadow_any_hit = 1;
     for (uint64_t i = 0; i < n_mat; i++) if (d->materials[i].kind == RT_MAT_DIELECTRIC) v.shadow_any_hit = 0;
+    // what classify_kernel (render.hip) finds out per tile by tracing 16 rays, where the scene's materials leave nothing to find out
+    v.uniform_cost_class = n_mat ? 0u : 0xffu;
+    for (uint64_t i = 0; i < n_mat; i++) {
+        const RtMaterial& m = d->materials[i];
+        const uint32_t c = m.kind == RT_MAT_DIELECTRIC ? 0u : ((m.kind == RT_MAT_SPECULAR || m.reflectivity > 0.0f) ? 1u : 2u);
+        if (i == 0) v.uniform_cost_class = c; else if (c != v.uniform_cost_class) v.uniform_cost_class = 0xffu;
+        if (v.uniform_cost_class == 0xffu) break;
+    }
     v.mesh_entities = d->mesh_object_count ? 1u : 0u;
     // Circle of confusion of any primary hit, bounded from the TLAS root box: camera rays meet the focal plane at
     // t = 1 and t is the depth along the view axis over the focus distance, rays of one pixel are 2 R |1 - t| apart at t
