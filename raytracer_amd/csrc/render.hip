@@ -1528,24 +1528,28 @@ __global__ void finish_kernel(const float* acc, uint32_t src_pitch, uint32_t sx,
 // The beam walks the trees the render kernel walks (any box it misses prunes everything below: inner boxes contain their leaves' boxes); into a mesh instance it goes as
 // Entity::hit takes a ray there (ray_to_entity on the central ray: translations and unit-axis rotations keep distances, so the radii stand; scenes with other axes -
 // loose_boxes - are not culled), and the first leaf box it meets - a sphere's or plane's entity box, a triangle leaf - ends the walk: not empty.
-struct Beam { float a[3], b[3]; float r_l, r_t, scale, bmax; };      // C(t) = a + t b; scale: the largest coordinate in play (the margin is relative to it)
+struct Beam {
+    float a[3], b[3];                 // C(t) = a + t b
+    float r_l, r_t, scale, bmax;      // scale: the largest coordinate in play (the margin is relative to it)
+    float p[2][3][2], ip[2][3][2];    // per piece and axis: the slopes of the two constraints p t >= q and their reciprocals - the same for every box the beam is tested against
+};
 
 __device__ __forceinline__ bool beam_meets_box(const Beam& B, const float lo[3], const float hi[3]) {
     float scale = B.scale;
     for (int i = 0; i < 3; i++) scale = fmaxf(scale, fmaxf(fabsf(lo[i]), fabsf(hi[i])));
     const float margin = 2.5e-4f * scale;          // 10^3 x the relative rounding of the per-ray slab test and of the ray transform
     for (int piece = 0; piece < 2; piece++) {
-        // rho'(t) = alpha + beta t >= rho(t) + margin on the piece (the slope's own margin covers what grows with t: the rounding of C(t), 1e-7 |b| t)
+        // rho'(t) = alpha + beta t >= rho(t) + margin on the piece (beta: beam_set_ray)
         const float alpha = (piece == 0 ? B.r_l : -B.r_l) + margin;
-        const float beta = piece == 0 ? (B.r_t - B.r_l) : (B.r_l + B.r_t) * 1.001f + 1.0e-5f * B.bmax;
         float t_lo = piece == 0 ? 0.0f : 1.0f, t_hi = piece == 0 ? 1.0f : RT_F32_MAX;
         bool none = false;
         for (int i = 0; i < 3; i++) {
             // inside the grown slab i:  a + t b + rho' >= lo  and  a + t b - rho' <= hi
-            const float p[2] = {B.b[i] + beta, beta - B.b[i]}, q[2] = {lo[i] - B.a[i] - alpha, B.a[i] - hi[i] - alpha};
+            const float q[2] = {lo[i] - B.a[i] - alpha, B.a[i] - hi[i] - alpha};
             for (int c = 0; c < 2; c++) {
-                if (p[c] > 0.0f) { const float r = q[c] / p[c]; t_lo = fmaxf(t_lo, r - fabsf(r) * 1.0e-5f); }
-                else if (p[c] < 0.0f) { const float r = q[c] / p[c]; t_hi = fminf(t_hi, r + fabsf(r) * 1.0e-5f); }
+                const float p = B.p[piece][i][c], r = q[c] * B.ip[piece][i][c];      // (q / p to 1.5 ulp: the slack below is a hundred times that)
+                if (p > 0.0f) t_lo = fmaxf(t_lo, r - fabsf(r) * 1.0e-5f);
+                else if (p < 0.0f) t_hi = fminf(t_hi, r + fabsf(r) * 1.0e-5f);
                 else if (q[c] > 0.0f) none = true;
             }
         }
@@ -1557,6 +1561,14 @@ __device__ __forceinline__ bool beam_meets_box(const Beam& B, const float lo[3],
 __device__ __forceinline__ void beam_set_ray(Beam& B, F3 a, F3 b) {
     B.a[0] = a.x; B.a[1] = a.y; B.a[2] = a.z; B.b[0] = b.x; B.b[1] = b.y; B.b[2] = b.z;
     B.bmax = fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fabsf(b.z));
+    for (int piece = 0; piece < 2; piece++) {
+        // rho'(t) = alpha + beta t: beta of beam_meets_box (the slope's own margin covers what grows with t: the rounding of C(t), 1e-7 |b| t)
+        const float beta = piece == 0 ? (B.r_t - B.r_l) : (B.r_l + B.r_t) * 1.001f + 1.0e-5f * B.bmax;
+        for (int i = 0; i < 3; i++) {
+            B.p[piece][i][0] = B.b[i] + beta; B.p[piece][i][1] = beta - B.b[i];
+            B.ip[piece][i][0] = 1.0f / B.p[piece][i][0]; B.ip[piece][i][1] = 1.0f / B.p[piece][i][1];      // (a zero slope never reads its reciprocal)
+        }
+    }
     B.scale = fmaxf(B.scale, fmaxf(fmaxf(fabsf(a.x) + fabsf(b.x), fabsf(a.y) + fabsf(b.y)), fabsf(a.z) + fabsf(b.z)));      // (only ever grows: the margin of the world beam stands inside an instance)
 }
 
@@ -2260,7 +2272,8 @@ int enqueue_accumulate(RtScene* scene, Workspace& ws, const RtSettings* st, cons
         tile_bin_dev = tile_bin;
         HIP_TRY(hipMemsetAsync(group_counts, 0, (size_t)n_groups * RT_GROUP_STRIDE * 4, stream));
         if (P.cull_empty) {
-            hipLaunchKernelGGL(empty_tiles_kernel, dim3((n_tiles + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), scene->stack_lds_bytes, stream, view, P, n_tiles, tile_bin);
+            // (workgroups of ONE wave: a tile's walk is one thread's chain of dependent reads - a rank's share of a 4K frame is 16 200 tiles, 64 workgroups of 256 on 256 CUs)
+            hipLaunchKernelGGL(empty_tiles_kernel, dim3((n_tiles + 63u) / 64u), dim3(64), scene->stack_lds_bytes, stream, view, P, n_tiles, tile_bin);
             HIP_TRY(hipGetLastError());
         }
         hipLaunchKernelGGL(classify_kernel, dim3((n_tiles * 16 + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), scene->stack_lds_bytes, stream, view, P,
