@@ -41,7 +41,8 @@ def differing(scene, oracle, st, chunk, rng_mode, seed):
     return int((d > ATOL).sum()), float(d.max())
 
 
-@pytest.mark.parametrize("seed", [385, 811, 927, 1503, 1823, 1875, 2322, 2486, 2812])
+@pytest.mark.parametrize("seed", [385, 811, 927, 1503, 1823, 1875, 2322, 2486, 2812,
+                                  50077])      # (seeds 50000-50599, re-entry session of round 3, final library: the one failure of 600)
 def test_scenes_the_fuzz_sweep_flagged(seed):
     """tools/fuzz_sweep.py's failures among seeds 0..2999 (tests/test_gpu_fuzz.py's gate: 80 x 48, depth 5, 3 spp, render seed = seed)."""
     b = random_scene(1000 + seed)
@@ -73,7 +74,8 @@ def sweep_case(seed):
 
 @pytest.mark.parametrize("seed,expect", [(1234, (147, 97, 64, 3, "stratified")), (1305, (93, 99, 64, 7, "stratified")),      # round 2's second sweep (seeds 1000-1399)
                                          (183, (145, 95, 33, 8, "stratified")), (198, (65, 81, 64, 7, "reference")),          # seeds 0-799, re-run in round 3 with the
-                                         (256, (71, 74, 17, 8, "stratified")), (275, (40, 93, 64, 7, "reference"))])         # 8 x 8 lens cells: the same four as in round 2
+                                         (256, (71, 74, 17, 8, "stratified")), (275, (40, 93, 64, 7, "reference")),          # 8 x 8 lens cells: the same four as in round 2
+                                         (40108, (113, 70, 24, 8, "reference")), (40377, (73, 62, 33, 8, "reference"))])     # seeds 40000-40399 on the final library (empty tiles, single-round claims): the same with those switched off
 def test_cases_the_invariant_sweep_flagged(seed, expect):
     b, w, h, spp, depth, lens_mode, render_seed = sweep_case(seed)
     assert (w, h, spp, depth, lens_mode) == expect
