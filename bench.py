@@ -53,6 +53,7 @@ The JSON line also carries
 """
 import argparse
 import json
+import math
 import os
 import socket
 import subprocess
@@ -345,9 +346,14 @@ def oracle_legs(m, args, n_gpus, cpu_leg=True, cpu_seconds=None):
     stride = max(1, int(round(W * H * spp / target)))
     if stride > 4:          # a sparse sample: many small chunks spread over the frame instead of a few large ones
         grid = (128, 128)
+        if grid[0] * grid[1] // stride < 200 and min(W, H) >= 1024:
+            grid = (512, 512)       # at least some hundred chunks however small the share: 31 chunks of mesh_demo's frame gave 7.5, 21 or 77 Mrays/s depending on where they fell
         n_chunks = grid[0] * grid[1]
-        if stride % 128 == 0 or stride % 2 == 0:
-            stride += 1     # odd and not a multiple of the row length: the picks walk across rows and columns
+        # the same chunks from run to run: the stride follows the host's measured speed, and on a frame whose chunks differ a hundredfold in cost (glass against sky) a
+        # slightly different stride draws a different sample - 7.5 against 21 Mrays/s on mesh_demo.  Quantised to a power of two times the golden ratio, made odd (the
+        # picks then form a lattice over rows and columns - a stride of 2^k + 1 would walk ONE diagonal of a 2^m-wide grid), the sample only changes when the host is
+        # twice as fast or slow.
+        stride = int(round((1 << max(2, int(round(math.log2(stride / 1.618)))) ) * 1.618)) | 1
     count = (n_chunks - 1) // stride
 
     def timed(n_threads):
