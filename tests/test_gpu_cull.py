@@ -190,3 +190,25 @@ def test_against_the_oracle_and_in_every_partition():
         total += cnt.cpu().numpy()
     assert np.array_equal(frame, rgb) and tuple(total) == cn
     scene.close()
+
+
+def test_single_round_claims_do_not_change_the_frame(tmp_path):
+    """Launches that hand out few blocks per resident wave claim single ROUNDS of a block (render.hip: RT_SINGLE_ROUNDS_BELOW; decided on the device, instantiations
+    without depth of field).  The switch is read once per process, so the C++ harness renders the frame three times in processes of their own: never, always, as decided."""
+    import json
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "raytracer_amd", "rt_render")
+    seen = {}
+    for mode in ("0", "1", None):
+        env = dict(os.environ)
+        env.pop("RT_SINGLE_ROUNDS", None)
+        if mode is not None:
+            env["RT_SINGLE_ROUNDS"] = mode
+        p = subprocess.run([exe, "--scene", "Dreadnaught", "--width", "640", "--height", "360", "--spp", "32", "--depth", "4", "--chunks", "2x1", "--threads", "1",
+                            "--out", str(tmp_path / f"f{mode}.ppm")], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr
+        info = json.loads(p.stdout.strip().splitlines()[-1])
+        seen[mode] = (info["fnv1a"], info["rays"]["primary"], info["rays"]["shadow"], info["rays"]["samples"])
+    assert seen["0"] == seen["1"] == seen[None], seen
